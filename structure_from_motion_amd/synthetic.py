@@ -1,0 +1,181 @@
+"""Seeded synthetic bundle-adjustment problems.
+
+The reference ships no datasets (``/root/reference/.gitignore:1``), so every
+benchmark / parity problem is synthetic: the *shape* (camera / point /
+observation counts, track-length statistics, intrinsics) follows the configs of
+BASELINE.json; the camera model is the reference's (rvec, t, fixed per-camera
+fx, fy, cx, cy, no distortion -- ``BundleAdjustment.py:136-142``).
+
+All generators return a dict of structure-of-arrays (the layout of the C-ABI
+``BaProblem``): cam_pose (Nc,6), cam_intr (Nc,4), cam_fixed (Nc,) uint8,
+points (Np,3), obs_cam (No,) int32, obs_pt (No,) int32, obs_xy (No,2).
+Observation order is camera-major, as ``prepare_observations_from_image_data``
+produces it (``BundleAdjustment.py:249-270``).
+"""
+import numpy as np
+
+from .geometry import matrix_to_rvec, project_points, rvec_to_matrix
+
+# (n_cams, n_points, n_obs) of the BASELINE.json configs
+SHAPES = {
+    "ladybug1723": (1723, 156502, 678718),
+    "venice1778": (1778, 993923, 5001946),
+    "city10k": (10000, 20000000, 100000000),
+}
+
+
+def _track_lengths(rng, n_points, n_obs, max_track, min_track=2):
+    mean = n_obs / n_points
+    L = min_track + rng.poisson(max(mean - min_track, 0.0), size=n_points)
+    L = np.clip(L, min_track, max_track).astype(np.int64)
+    diff = int(n_obs - L.sum())
+    # hit n_obs exactly: nudge random points by +-1 inside [min_track, max_track]
+    while diff != 0:
+        step = 1 if diff > 0 else -1
+        ok = np.flatnonzero((L + step >= min_track) & (L + step <= max_track))
+        k = min(abs(diff), len(ok))
+        if k == 0:
+            break
+        pick = rng.choice(ok, size=k, replace=False)
+        L[pick] += step
+        diff -= step * k
+    return L
+
+
+def _finish(rng, cam_pose_gt, cam_intr, points_gt, obs_cam, obs_pt, noise, outlier_frac,
+            sig_r, sig_t, sig_p, cam_fixed, shuffle_in_cam=True):
+    n_obs = len(obs_cam)
+    xy = project_points(cam_pose_gt, cam_intr, points_gt, obs_cam, obs_pt)
+    xy += rng.normal(0.0, noise, size=xy.shape)
+    if outlier_frac > 0:
+        bad = rng.random(n_obs) < outlier_frac
+        nb = int(bad.sum())
+        ang = rng.uniform(0, 2 * np.pi, nb)
+        mag = rng.uniform(5.0, 50.0, nb)
+        xy[bad] += np.stack([mag * np.cos(ang), mag * np.sin(ang)], axis=1)
+    # camera-major observation order (then arbitrary "keypoint" order inside a camera)
+    key = obs_cam.astype(np.int64) * (1 << 32) + (rng.permutation(n_obs) if shuffle_in_cam else np.arange(n_obs))
+    order = np.argsort(key, kind="stable")
+    obs_cam, obs_pt, xy = obs_cam[order], obs_pt[order], xy[order]
+    cam_pose = cam_pose_gt.copy()
+    free = ~cam_fixed.astype(bool)
+    cam_pose[free, :3] += rng.normal(0.0, sig_r, size=(int(free.sum()), 3))
+    cam_pose[free, 3:] += rng.normal(0.0, sig_t, size=(int(free.sum()), 3))
+    points = points_gt + rng.normal(0.0, 1.0, size=points_gt.shape) * sig_p
+    return dict(cam_pose=np.ascontiguousarray(cam_pose), cam_intr=np.ascontiguousarray(cam_intr),
+                cam_fixed=cam_fixed.astype(np.uint8), points=np.ascontiguousarray(points),
+                obs_cam=np.ascontiguousarray(obs_cam, dtype=np.int32),
+                obs_pt=np.ascontiguousarray(obs_pt, dtype=np.int32),
+                obs_xy=np.ascontiguousarray(xy),
+                cam_pose_gt=cam_pose_gt, points_gt=points_gt)
+
+
+def make_street(n_cams, n_points, n_obs, seed=0, noise=0.5, outlier_frac=0.01, max_track=16,
+                n_fixed=1, sig_r=1e-3, sig_t=1e-2, sig_p_rel=1e-2, point_offset=0, cam_seed=None):
+    """BAL-shaped problem: cameras on a street trajectory (baseline 1), points in a slab at
+    depth 5..50 baselines, each observed by a contiguous window of cameras whose length follows
+    2 + Poisson so that the mean track is n_obs / n_points.  ``cam_seed`` fixes the cameras
+    independently of the points (used to generate point shards of one problem per rank)."""
+    rng = np.random.default_rng(seed)
+    crng = np.random.default_rng(seed if cam_seed is None else cam_seed)
+    max_track = min(max_track, n_cams)
+    # cameras: centre (i, ~0, ~0), looking down +z with a small random rotation
+    C = np.stack([np.arange(n_cams, dtype=np.float64),
+                  crng.normal(0, 0.05, n_cams), crng.normal(0, 0.05, n_cams)], axis=1)
+    rv = crng.normal(0.0, 0.02, size=(n_cams, 3))
+    R = rvec_to_matrix(rv)
+    t = -np.einsum("nij,nj->ni", R, C)
+    cam_pose_gt = np.concatenate([rv, t], axis=1)
+    f = crng.uniform(800.0, 1600.0, n_cams)
+    cam_intr = np.stack([f, f, np.full(n_cams, 960.0), np.full(n_cams, 540.0)], axis=1)
+    L = _track_lengths(rng, n_points, n_obs, max_track)
+    start = (rng.random(n_points) * (n_cams - L + 1)).astype(np.int64)
+    centre = start + 0.5 * (L - 1)
+    depth = rng.uniform(5.0, 50.0, n_points)
+    points_gt = np.stack([centre + rng.uniform(-1.0, 1.0, n_points),
+                          rng.uniform(-3.0, 3.0, n_points), depth], axis=1)
+    obs_pt = np.repeat(np.arange(n_points, dtype=np.int64), L)
+    first = np.cumsum(L) - L
+    within = np.arange(len(obs_pt), dtype=np.int64) - np.repeat(first, L)
+    obs_cam = np.repeat(start, L) + within
+    cam_fixed = np.zeros(n_cams, dtype=np.uint8)
+    cam_fixed[:n_fixed] = 1
+    prob = _finish(rng, cam_pose_gt, cam_intr, points_gt, obs_cam, obs_pt, noise, outlier_frac,
+                   sig_r, sig_t, sig_p_rel * depth[:, None], cam_fixed)
+    prob["name"] = f"street(nc={n_cams},np={n_points},no={len(obs_pt)},seed={seed})"
+    return prob
+
+
+def make_ring(n_cams, n_points, seed=0, K=(1520.4, 1525.9, 302.32, 246.87), focal_jitter=0.02,
+              noise=0.35, outlier_frac=0.0, visibility="dense", mean_track=4.0, n_fixed=1,
+              n_seed_points=None, radius=4.0, sig_r=1e-3, sig_t=1e-2, sig_p=1e-2, n_unobserved=0):
+    """Temple / Fountain-shaped problem: cameras on a ring (or arc) of ``radius`` looking at a
+    unit blob of points.
+
+    visibility='dense': each point is seen by a contiguous window of ring cameras (mean length
+    ``mean_track``).  visibility='sfm': what the reference's driver actually produces
+    (SURVEY.md H4): the first ``n_seed_points`` points have 2 observations (cameras 0 and 1),
+    every other point exactly 1 (``Reconstruction.py:41-47, 244-251``)."""
+    rng = np.random.default_rng(seed)
+    ang = np.linspace(0.0, 2 * np.pi, n_cams, endpoint=False) if n_cams > 12 else np.linspace(-0.9, 0.9, n_cams)
+    C = np.stack([radius * np.sin(ang), rng.normal(0, 0.05, n_cams), -radius * np.cos(ang)], axis=1)
+    cam_pose_gt = np.zeros((n_cams, 6))
+    for i in range(n_cams):
+        zax = -C[i] / np.linalg.norm(C[i])
+        xax = np.cross([0.0, 1.0, 0.0], zax); xax /= np.linalg.norm(xax)
+        yax = np.cross(zax, xax)
+        Rm = np.stack([xax, yax, zax], axis=0)  # world -> camera
+        cam_pose_gt[i, :3] = matrix_to_rvec(Rm)
+        cam_pose_gt[i, 3:] = -Rm @ C[i]
+    fj = 1.0 + rng.uniform(-focal_jitter, focal_jitter, n_cams)
+    cam_intr = np.stack([K[0] * fj, K[1] * fj, np.full(n_cams, K[2]), np.full(n_cams, K[3])], axis=1)
+    n_obs_pts = n_points - n_unobserved
+    points_gt = rng.normal(0.0, 0.45, size=(n_points, 3))
+    if visibility == "dense":
+        n_obs = int(round(mean_track * n_obs_pts))
+        L = _track_lengths(rng, n_obs_pts, n_obs, max_track=min(n_cams, 24))
+        # window centred on the camera nearest to the point's azimuth
+        az = np.arctan2(points_gt[:n_obs_pts, 0], -points_gt[:n_obs_pts, 2])
+        near = np.argmin(np.abs(((az[:, None] - ang[None, :] + np.pi) % (2 * np.pi)) - np.pi), axis=1)
+        start = near - L // 2
+        obs_pt = np.repeat(np.arange(n_obs_pts, dtype=np.int64), L)
+        first = np.cumsum(L) - L
+        within = np.arange(len(obs_pt), dtype=np.int64) - np.repeat(first, L)
+        if n_cams > 12:
+            obs_cam = (np.repeat(start, L) + within) % n_cams
+        else:
+            start = np.clip(start, 0, n_cams - L)
+            obs_cam = np.repeat(start, L) + within
+    elif visibility == "sfm":
+        ns = n_obs_pts // 8 if n_seed_points is None else n_seed_points
+        pt_a = np.arange(ns, dtype=np.int64)
+        rest = np.arange(ns, n_obs_pts, dtype=np.int64)
+        cam_rest = 2 + (np.arange(len(rest)) * (n_cams - 2) // max(len(rest), 1))
+        obs_pt = np.concatenate([pt_a, pt_a, rest])
+        obs_cam = np.concatenate([np.zeros(ns, np.int64), np.ones(ns, np.int64), cam_rest.astype(np.int64)])
+    else:
+        raise ValueError(visibility)
+    cam_fixed = np.zeros(n_cams, dtype=np.uint8)
+    cam_fixed[:n_fixed] = 1
+    prob = _finish(rng, cam_pose_gt, cam_intr, points_gt, obs_cam, obs_pt, noise, outlier_frac,
+                   sig_r, sig_t, sig_p, cam_fixed)
+    prob["name"] = f"ring(nc={n_cams},np={n_points},no={len(obs_pt)},vis={visibility},seed={seed})"
+    return prob
+
+
+def make_config(name, seed=None, scale=1.0):
+    """The BASELINE.json configs as concrete problems.  ``scale`` < 1 shrinks points and
+    observations proportionally (parity tests use reduced sizes; the bench uses 1.0)."""
+    if name in ("fountain", "C1"):
+        return make_ring(11, int(16908 * scale), seed=1235 if seed is None else seed,
+                         K=(2759.48 * 1600 / 3072, 2764.16 * 1600 / 3072, 1520.69 * 1600 / 3072, 1006.81 * 1600 / 3072),
+                         focal_jitter=0.0, noise=0.4, mean_track=3.5, n_fixed=2)
+    if name in ("temple", "C2"):
+        return make_ring(47, int(20467 * scale), seed=1236 if seed is None else seed, focal_jitter=0.02,
+                         noise=0.35, mean_track=4.0, n_fixed=1)
+    if name in SHAPES:
+        nc, np_, no = SHAPES[name]
+        idx = {"ladybug1723": 3, "venice1778": 4, "city10k": 5}[name]
+        return make_street(nc, max(int(np_ * scale), 16), max(int(no * scale), 32),
+                           seed=1233 + idx if seed is None else seed)
+    raise ValueError(f"unknown config {name!r}")
