@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""Benchmark of the bundle-adjustment hot path on MI355X (contract: see the task brief).
+
+A "step" is ONE residual + Jacobian + Schur-complement build pass (x, lambda) -> (cost, reduced
+camera system, reduced gradient) over the whole synthetic problem, inputs already resident in HBM.
+
+  python bench.py                         # 1 GPU, Venice-1778-shaped problem (BASELINE.json configs[3])
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+N > 1: weak scaling -- every rank owns a Venice-sized point shard (993 923 points, ~5.0 M
+observations) of ONE problem with the 1778 cameras replicated; per step the ranks all-reduce the
+reduced camera system over RCCL.  value = observations of all ranks / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes(n_obs, n_pts, n_cams):
+    """one build pass, each array touched once = 40 B/obs + 96 B/point + 296 B/camera."""
+    return 40.0 * n_obs + 96.0 * n_pts + 296.0 * n_cams
+
+
+def cpu_baseline(prob, budget_obs):
+    """The reference's scipy configuration (oracle/scipy_path.py, a from-scratch port) timed on this
+    host: f(x) + one residual sweep per colour group = one finite-difference Jacobian, on a bounded
+    sample (the first points of the workload and all their observations)."""
+    from oracle import scipy_path
+    cnt = np.bincount(prob["obs_pt"], minlength=len(prob["points"]))
+    n_pts = int(np.searchsorted(np.cumsum(cnt), budget_obs)) + 1
+    m = prob["obs_pt"] < n_pts
+    sample = dict(cam_pose=prob["cam_pose"], cam_intr=prob["cam_intr"], cam_fixed=prob["cam_fixed"],
+                  points=prob["points"][:n_pts], obs_cam=prob["obs_cam"][m], obs_pt=prob["obs_pt"][m],
+                  obs_xy=prob["obs_xy"][m])
+    r = scipy_path.time_linearisation(sample)
+    return {"value": r["obs_per_s"], "unit": "observations/sec", "cores": 1, "kind": "port",
+            "sample": f"first {n_pts} points / {r['n_obs']} observations of the workload, residual closure + "
+                      f"2-point sparse Jacobian = {r['sweeps']} residual sweeps in {r['seconds']:.1f} s "
+                      f"(host has {os.cpu_count()} cores, the path is single-threaded Python)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="venice1778")
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink points/observations (debug only)")
+    ap.add_argument("--lm-steps", type=int, default=10)
+    ap.add_argument("--cpu-sample-obs", type=int, default=150000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from structure_from_motion_amd import _capi, synthetic
+    from structure_from_motion_amd import dist as badist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    nc, n_pts, n_obs = synthetic.SHAPES[args.workload]
+    n_pts, n_obs = max(int(n_pts * args.scale), 64), max(int(n_obs * args.scale), 256)
+    # one problem; rank r owns point shard r (own seed), cameras identical on every rank (cam_seed)
+    idx = {"ladybug1723": 3, "venice1778": 4, "city10k": 5}[args.workload]
+    prob = synthetic.make_street(nc, n_pts, n_obs, seed=1233 + idx + 1000 * rank, cam_seed=1233 + idx)
+    arr = _capi.Arrays.from_dict(prob)
+    lam = 1e-4
+    opts = dict(loss="huber", f_scale=1.0, max_iter=300, device=local_rank)
+    if world > 1:
+        h = badist.create_sharded_handle(prob, rank, world, **opts)
+    else:
+        h = _capi.Handle(arr, **opts)
+
+    def barrier():
+        h.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    h.build_bench(lam, warmup=0, reps=max(args.warmup, 1))  # W untimed warm-up steps
+    barrier()
+    t0 = time.perf_counter()
+    h._lib.ba_build_bench(h.h, lam, 0, args.steps, None, None)  # exactly K steps, no host syncs in between
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt * 1e3 / args.steps
+    total_obs = n_obs * world
+    value = total_obs / (dt / args.steps)
+
+    # dominant kernel: HIP events around its launch on the library's stream (per-rank shard)
+    _, ms_kernel = h.build_bench(lam, warmup=0, reps=min(args.steps, 10))
+    alg = algorithmic_bytes(n_obs, n_pts, nc)
+    achieved = alg / (ms_kernel * 1e-3) / 1e9
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tf):
+        traffic = json.load(open(tf)).get(f"{args.workload}@{args.scale:g}")
+    roofline = {"bound": "hbm", "kernel": "k_build", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg, "kernel_ms": ms_kernel}
+
+    # full LM iterations (build + PCG + back-substitution + trial cost + device-side accept logic)
+    barrier()
+    t0 = time.perf_counter()
+    summ = h.run(args.lm_steps)
+    barrier()
+    lm_dt = time.perf_counter() - t0
+    lm_rate = max(summ["iterations"], 1) / lm_dt
+
+    out = {
+        "metric": "observations/sec (residual+Jacobian+Schur build)", "value": value, "unit": "observations/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{args.workload} shape per GPU: {nc} cameras (replicated), {n_pts} points, "
+                               f"{n_obs} observations per rank; huber f_scale=1.0; lambda={lam:g}",
+                   "scale": args.scale, "cameras": nc, "points_per_gpu": n_pts, "observations_per_gpu": n_obs,
+                   "parallelism": f"point-sharded x{world}" if world > 1 else "single GPU"},
+        "lm_iters_per_sec": lm_rate, "lm_steps": summ["iterations"], "lm_pcg_iterations": summ["pcg_iterations"],
+        "lm_cost": [summ["initial_cost"], summ["final_cost"]],
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(prob, args.cpu_sample_obs)
+    h.close()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,169 @@
+/*
+ * ba_hip.h -- C ABI of the MI355X (gfx950) bundle-adjustment engine.
+ *
+ * Drop-in boundary for the global / final bundle adjustment of the reference
+ * project (AhaanB29/Structure_from_Motion, src/BundleAdjustment.py).  The
+ * reference has no FFI: its operator API is the Python module
+ * `BundleAdjustment` (7 public functions).  The Python shim
+ * `structure_from_motion_amd/BundleAdjustment.py` keeps those signatures and
+ * binds the entry points below with ctypes (INTEGRATION.md shows the stub).
+ * Every entry point is plain C: pointers + sizes, no exceptions, no torch types;
+ * the return value is 0 (BA_OK) or a negative BA_ERR_* code, and
+ * ba_last_error() returns the message of the last failure on the calling thread.
+ *
+ * Data layout (structure of arrays, fp64 / int32) -- the reference's parameter
+ * vector and observation list (BundleAdjustment.py:46-65, 129-146, 243-272):
+ *   cam_pose  [n_cams*6]   rvec(3), t(3) per camera, camera order = list(cameras.keys()) (:30)
+ *   cam_intr  [n_cams*4]   fx, fy, cx, cy: the entries of K that cv2.projectPoints reads (:136,:142)
+ *   cam_fixed [n_cams]     1 = gauge-anchored camera, kept constant (:34-38, :53)
+ *   points    [n_points*3] xyz of EVERY point, observed or not (:62-63)
+ *   obs_cam   [n_obs]      camera index of each observation (position in the camera order)
+ *   obs_pt    [n_obs]      point index (:131)
+ *   obs_xy    [n_obs*2]    observed pixel (:132)
+ * Residuals are interleaved (du, dv) in observation order (:145-152).
+ */
+#ifndef BA_HIP_H
+#define BA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BA_OK 0
+#define BA_ERR_INVALID (-1)     /* bad argument (null pointer, index out of range, ...) */
+#define BA_ERR_HIP (-2)         /* a HIP runtime call failed / no device */
+#define BA_ERR_UNSUPPORTED (-3) /* e.g. a point with more than BA_MAX_TRACK observations */
+#define BA_ERR_NOMEM (-4)
+#define BA_ERR_NUMERIC (-5)     /* non-finite initial cost */
+#define BA_ERR_COMM (-6)        /* the all-reduce callback reported a failure */
+
+#define BA_MAX_TRACK 256 /* longest supported track (observations of one point) */
+
+/* loss kinds = what scipy.optimize.least_squares accepts (scipy _lsq/least_squares.py:208-209);
+ * the reference only uses 'huber' (BundleAdjustment.py:332, :367). */
+enum { BA_LOSS_LINEAR = 0, BA_LOSS_SOFT_L1 = 1, BA_LOSS_HUBER = 2, BA_LOSS_CAUCHY = 3, BA_LOSS_ARCTAN = 4 };
+enum { BA_SOLVER_AUTO = 0, BA_SOLVER_PCG = 1, BA_SOLVER_DENSE_CHOLESKY = 2 };
+enum { BA_MEM_HOST = 0, BA_MEM_DEVICE = 1 };
+enum { BA_REDUCE_SUM = 0, BA_REDUCE_MAX = 1, BA_BROADCAST0 = 2 };
+
+/* The problem: replaces the (cameras, points_3d, observations, visited_ids) arguments of
+ * global_bundle_adjustment (BundleAdjustment.py:7-9) after marshalling to arrays. */
+typedef struct BaProblem {
+    int32_t n_cams;
+    int32_t n_points;
+    int64_t n_obs;
+    double *cam_pose;         /* in/out */
+    const double *cam_intr;
+    const uint8_t *cam_fixed;
+    double *points;           /* in/out */
+    const int32_t *obs_cam;
+    const int32_t *obs_pt;
+    const double *obs_xy;
+    int32_t memory;           /* BA_MEM_HOST or BA_MEM_DEVICE: where ALL the pointers above live */
+    int32_t reserved;
+} BaProblem;
+
+/* Solver options: the keyword arguments the reference passes to least_squares
+ * (BundleAdjustment.py:210-220) plus the engine's own knobs. */
+typedef struct BaOptions {
+    int32_t loss;          /* BA_LOSS_*            <- robust_loss (:213) */
+    int32_t max_iter;      /* LM trial steps       <- max_nfev (:215; counts trial steps, scipy least_squares.py:482) */
+    double f_scale;        /*                      <- loss_f_scale (:214) */
+    double ftol, xtol, gtol; /*                    <- 1e-8 each (:216-218) */
+    double lambda0;        /* initial LM damping (default 1e-4) */
+    double pcg_tol;        /* relative residual of the reduced-camera-system solve (default 1e-8) */
+    int32_t pcg_max_iter;  /* default 500 */
+    int32_t linear_solver; /* BA_SOLVER_* */
+    int32_t verbose;       /* 0 silent, 1 summary, 2 per-iteration table (<- verbose, :219) */
+    int32_t device;        /* HIP device ordinal; -1 = current device */
+    int32_t deterministic; /* reserved (0) */
+    int32_t reserved;
+} BaOptions;
+
+/* Result: the fields of scipy's OptimizeResult that the reference reads (:223-230). */
+typedef struct BaSummary {
+    int32_t status;        /* scipy codes: 0 max_iter, 1 gtol, 2 ftol, 3 xtol, 4 ftol+xtol (scipy _lsq/common.py:705-717); <0 BA_ERR_* */
+    int32_t iterations;    /* LM trial steps taken (= nfev - 1) */
+    int32_t accepted;      /* accepted steps */
+    int32_t pcg_iterations;/* total PCG iterations */
+    double initial_cost;   /* 0.5 * sum rho, scipy least_squares.py:220-227 */
+    double final_cost;
+    double grad_inf;       /* ||J^T (rho' f)||_inf = 'optimality' */
+    double residual_sum;   /* signed sum of the final residuals (the reference's success quirk, :223-224) */
+    double lambda_final;
+    double t_setup_ms, t_solve_ms;
+    int64_t n_chunks, nnz_blocks;
+} BaSummary;
+
+/* Structure statistics of the host-side symbolic analysis (no GPU needed). */
+typedef struct BaAnalysis {
+    int64_t n_chunks, n_pair_entries, nnz_blocks_upper, nnz_blocks_full;
+    int64_t n_direct_pairs, n_direct_cam_obs; /* contributions that bypass the LDS tiles */
+    int32_t n_free_cams, n_observed_points, max_track, max_chunk_cams, max_chunk_pairs, reserved;
+    double mean_track;
+} BaAnalysis;
+
+typedef struct BaHandle BaHandle;
+
+/* Collective hook for point-sharded multi-GPU solves: called with a DEVICE
+ * pointer after the library has synchronised its stream; must return 0 on success and only
+ * after the result is visible to later work on any stream.  op = BA_REDUCE_* / BA_BROADCAST0. */
+typedef int (*BaCollectiveFn)(void *dev_ptr, int64_t count_f64, int32_t op, void *user);
+
+int ba_version(void);
+const char *ba_last_error(void);
+void ba_default_options(BaOptions *opt);
+
+/* ---- one-shot entry points --------------------------------------------------------- */
+/* Replaces the least_squares(...) call + pack/unpack of global_bundle_adjustment
+ * (BundleAdjustment.py:200-226).  On status >= 0 cam_pose / points are overwritten with the
+ * optimised values (free cameras and all points); on error they are left untouched. */
+int ba_solve(BaProblem *prob, const BaOptions *opt, BaSummary *out);
+/* Replaces residuals(params) (BundleAdjustment.py:102-152): out[2*n_obs], caller's order. */
+int ba_eval_residuals(const BaProblem *prob, double *out_residuals);
+/* Replaces the objective scipy builds from it (least_squares.py:220-227). */
+int ba_eval_cost(const BaProblem *prob, int32_t loss, double f_scale, double *out_cost);
+/* Replaces the finite-difference Jacobian over jac_sparsity (BundleAdjustment.py:154-198, :212):
+ * the non-zero blocks, jc[n_obs*12] = d(du,dv)/d(rvec,t) (2x6 row-major), jp[n_obs*6] (2x3). */
+int ba_eval_jacobian_blocks(const BaProblem *prob, double *out_jc, double *out_jp);
+/* Replaces compute_ba_reprojection_errors + utils.ReprojectionError (BundleAdjustment.py:388-423,
+ * utils.py:271-276): mean L2 error per camera with the FULL 3x3 K (cam_k[n_cams*9]); cameras
+ * without observations get NaN. */
+int ba_eval_reprojection_errors(const BaProblem *prob, const double *cam_k, double *out_err);
+
+/* Host-only structure analysis (runs without a GPU). */
+int ba_analyze(const BaProblem *prob, BaAnalysis *out);
+
+/* ---- handle API: problem resident on the device across calls ------------------------ */
+BaHandle *ba_create(const BaProblem *prob, const BaOptions *opt);
+void ba_destroy(BaHandle *h);
+/* Extra co-visibility pairs (free-camera index pairs i<=j, 2*n_pairs int32) to add to the
+ * reduced-camera-system pattern: ranks of a sharded solve must share ONE pattern.  Must be
+ * called before the first build. ba_get_pattern returns this rank's own pairs. */
+int ba_get_pattern(BaHandle *h, int32_t *out_pairs, int64_t capacity, int64_t *n_pairs);
+int ba_set_pattern(BaHandle *h, const int32_t *pairs, int64_t n_pairs);
+int ba_set_collective(BaHandle *h, BaCollectiveFn fn, void *user, int32_t rank, int32_t world);
+/* One residual + Jacobian + Schur-complement pass at the current state with damping lambda:
+ * (x, lambda) -> cost, reduced camera system S, reduced gradient.  The benchmark unit. */
+int ba_build(BaHandle *h, double lambda);
+/* Timed loop of ba_build with HIP events on the library's stream: average ms per pass and per
+ * launch of the dominant (fused linearise+Schur) kernel. */
+int ba_build_bench(BaHandle *h, double lambda, int32_t warmup, int32_t reps, double *ms_per_pass,
+                   double *ms_fused_kernel);
+/* Up to max_steps LM trial steps (continues from the current state); fills *out. */
+int ba_run(BaHandle *h, int32_t max_steps, BaSummary *out);
+int ba_get_state(BaHandle *h, double *cam_pose, double *points); /* host pointers, caller's order */
+int ba_get_cost(BaHandle *h, double *cost);
+/* Parity probes (host pointers, any may be NULL): dense reduced system s[(6Nf)^2] row-major,
+ * g_red[6Nf], per-camera u[n_cams*36] and g_c[n_cams*6], per-point v[n_points*9] (undamped)
+ * and g_p[n_points*3] of the last ba_build. */
+int ba_get_reduced_system(BaHandle *h, double *s, double *g_red, double *u, double *g_c, double *v,
+                          double *g_p);
+int ba_synchronize(BaHandle *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BA_HIP_H */

@@ -1,0 +1,280 @@
+"""Drop-in replacement for the reference's ``BundleAdjustment`` module, backed by the MI355X engine.
+
+Same seven public names, call signatures, return containers and error behaviour as
+``/root/reference/src/BundleAdjustment.py`` so that ``Reconstruction.py``'s
+``from BundleAdjustment import *`` (``Reconstruction.py:9``) and its calls
+(``inter_ba`` ``:253-255``, ``compute_ba_reprojection_errors`` ``:263``, ``final_ba``
+``:302-304``) run unchanged.  What differs is behind the boundary: instead of
+``scipy.optimize.least_squares`` with a finite-difference Jacobian over a Python residual loop
+(``BundleAdjustment.py:102-152, 210-220``) the solve is a Levenberg-Marquardt / Schur-complement
+engine in hand-written HIP (``csrc/``), reached through the C ABI of ``include/ba_hip.h``.
+
+There is no CPU fallback: without ``libba_hip.so`` and a GPU the solve raises inside the
+``try`` below and -- exactly like any other failure in the reference (``:238-240``) -- is
+reported as ``[BA] Bundle adjustment error: ...`` with ``(cameras, points_3d, False)``.
+"""
+import numpy as np
+
+from . import _capi
+from .geometry import matrix_to_rvec, rvec_to_matrix
+
+__all__ = [
+    "global_bundle_adjustment", "prepare_observations_from_image_data", "prepare_cameras_from_image_data",
+    "update_image_data_from_ba_results", "inter_ba", "final_ba", "compute_ba_reprojection_errors",
+]
+
+# Last engine summary (status, iterations, costs, timings) -- extra, not part of the reference API.
+last_summary = None
+
+
+def _anchor_ids(cam_ids, visited_ids):
+    """Gauge rule of BundleAdjustment.py:34-38: the first visited camera is always fixed, the
+    second one too while fewer than 15 images are registered."""
+    first = visited_ids[0] if len(visited_ids) > 0 else cam_ids[0]
+    second = visited_ids[1] if len(visited_ids) > 1 else cam_ids[1]
+    return first, second, len(visited_ids) < 15
+
+
+def _to_arrays(cameras, points_3d, observations, cam_ids, fixed_ids):
+    """dict / list containers -> structure of arrays (the layout of ``BaProblem``)."""
+    n_c = len(cam_ids)
+    index_of = {cid: i for i, cid in enumerate(cam_ids)}
+    cam_pose = np.empty((n_c, 6))
+    cam_intr = np.empty((n_c, 4))
+    cam_fixed = np.zeros(n_c, dtype=np.uint8)
+    for i, cid in enumerate(cam_ids):
+        cam = cameras[cid]
+        cam_pose[i, :3] = matrix_to_rvec(cam["R"])
+        cam_pose[i, 3:] = np.asarray(cam["t"], dtype=np.float64).reshape(3)
+        K = np.asarray(cam["K"], dtype=np.float64)
+        cam_intr[i] = (K[0, 0], K[1, 1], K[0, 2], K[1, 2])
+        cam_fixed[i] = cid in fixed_ids
+    n_p = len(points_3d)
+    points = np.empty((n_p, 3))
+    for i, p in enumerate(points_3d):
+        points[i, 0], points[i, 1], points[i, 2] = p[0], p[1], p[2]
+    n_o = len(observations)
+    obs_cam = np.empty(n_o, dtype=np.int32)
+    obs_pt = np.empty(n_o, dtype=np.int32)
+    obs_xy = np.empty((n_o, 2))
+    for k, ob in enumerate(observations):
+        obs_cam[k] = index_of[ob["camera_id"]]
+        obs_pt[k] = ob["point_idx"]
+        obs_xy[k] = ob["pixel"]
+    if n_o and (obs_pt.min() < 0 or obs_pt.max() >= n_p):
+        raise KeyError(int(obs_pt.max()))  # the reference's point_coords[point_idx] lookup fails the same way (:137)
+    return _capi.Arrays(cam_pose, cam_intr, cam_fixed, points, obs_cam, obs_pt, obs_xy)
+
+
+def global_bundle_adjustment(cameras, points_3d, observations, visited_ids,
+                             robust_loss='huber', loss_f_scale=1.0,
+                             max_nfev=100, verbose=0):
+    """Global bundle adjustment with gauge anchoring over camera (rvec, t) and 3D points.
+
+    Args / returns as the reference (BundleAdjustment.py:7-21):
+        cameras      {img_id: {'R': 3x3, 't': 3x1, 'K': 3x3}}
+        points_3d    [[x, y, z, r, g, b], ...]
+        observations [{'camera_id', 'point_idx', 'pixel'}, ...]
+        visited_ids  camera ids in registration order (decides the anchors)
+    Returns (optimized_cameras, optimized_points, success); on failure the ORIGINAL
+    ``cameras`` / ``points_3d`` objects are returned with ``False``.
+    """
+    global last_summary
+    if len(cameras) < 3 or len(points_3d) < 10:
+        print(f"[BA] Insufficient data: {len(cameras)} cameras, {len(points_3d)} points")
+        return cameras, points_3d, False
+
+    print(f"[BA] Starting BA with {len(cameras)} cameras, {len(points_3d)} points, {len(observations)} observations")
+
+    cam_ids = list(cameras.keys())
+    first_id, second_id, anchor_second = _anchor_ids(cam_ids, visited_ids)
+    fixed_ids = {first_id, second_id} if anchor_second else {first_id}
+    if verbose:
+        print(f"[BA] Anchoring cameras: {[first_id, second_id] if anchor_second else [first_id]}")
+
+    try:
+        n_free = sum(1 for c in cam_ids if c not in fixed_ids)
+        if 6 * n_free + 3 * len(points_3d) == 0:
+            if verbose:
+                print("[BA] All cameras anchored, no optimization needed")
+            return cameras, points_3d, True
+
+        arr = _to_arrays(cameras, points_3d, observations, cam_ids, fixed_ids)
+        summary = _capi.solve(arr, loss=robust_loss, f_scale=float(loss_f_scale), max_iter=int(max_nfev),
+                              ftol=1e-8, xtol=1e-8, gtol=1e-8, verbose=2 if verbose else 0)
+        last_summary = summary
+
+        # scipy's result.success is status > 0; the reference additionally accepts a result whose cost
+        # is below 0.95 x the signed sum of the residuals (BundleAdjustment.py:223-224).
+        converged = summary["status"] > 0
+        if converged or summary["final_cost"] < summary["residual_sum"] * 0.95:
+            new_cameras = {}
+            R_new = rvec_to_matrix(arr.cam_pose[:, :3])
+            for i, cid in enumerate(cam_ids):
+                if cid in fixed_ids:
+                    new_cameras[cid] = cameras[cid].copy()
+                else:
+                    new_cameras[cid] = {"R": R_new[i].copy(), "t": arr.cam_pose[i, 3:].reshape(3, 1).copy(),
+                                        "K": cameras[cid]["K"].copy()}
+            new_points = [[arr.points[i, 0], arr.points[i, 1], arr.points[i, 2], p[3], p[4], p[5]]
+                          for i, p in enumerate(points_3d)]
+            if verbose:
+                status = "converged" if converged else "improved significantly"
+                print(f"[BA] Bundle adjustment {status}! Cost: {summary['final_cost']:.6f}")
+            return new_cameras, new_points, True
+        if verbose:
+            print(f"[BA] Bundle adjustment failed: status {summary['status']} after {summary['iterations']} steps")
+        return cameras, points_3d, False
+
+    except Exception as e:  # the reference maps every failure to (inputs, False) (:238-240)
+        print(f"[BA] Bundle adjustment error: {e}")
+        return cameras, points_3d, False
+
+
+def _valid_track_entries(cam_data, n_points):
+    """(keypoint index, point index) pairs of one image that the reference would use
+    (BundleAdjustment.py:260-264): reference set, keypoint exists, a Python int, in range."""
+    _R, _t, _K, ref_array, _desc, kp = cam_data[:6]
+    n_kp = len(kp)
+    for kp_idx, point_idx in enumerate(ref_array):
+        if point_idx != -1 and kp_idx < n_kp and isinstance(point_idx, int) and 0 <= point_idx < n_points:
+            yield kp_idx, point_idx
+
+
+def prepare_observations_from_image_data(image_data, visited_ids, all_points_3D):
+    """image_data tuples -> observation dicts, camera-major in ``visited_ids`` order, keypoint
+    order inside a camera (BundleAdjustment.py:243-272).  This defines the residual order."""
+    observations = []
+    n_points = len(all_points_3D)
+    for img_id in visited_ids:
+        if img_id not in image_data:
+            continue
+        cam_data = image_data[img_id]
+        if len(cam_data) < 6:
+            continue
+        kp = cam_data[5]
+        for kp_idx, point_idx in _valid_track_entries(cam_data, n_points):
+            observations.append({"camera_id": img_id, "point_idx": point_idx,
+                                 "pixel": np.array(kp[kp_idx].pt, dtype=np.float64)})
+    return observations
+
+
+def prepare_cameras_from_image_data(image_data, visited_ids):
+    """image_data tuples -> cameras dict in ``visited_ids`` order, float64, t as (3,1)
+    (BundleAdjustment.py:275-295)."""
+    cameras = {}
+    for img_id in visited_ids:
+        if img_id not in image_data:
+            continue
+        cam_data = image_data[img_id]
+        if len(cam_data) < 6:
+            continue
+        R, t, K = cam_data[0], cam_data[1], cam_data[2]
+        cameras[img_id] = {"R": R.astype(np.float64), "t": t.astype(np.float64).reshape(3, 1), "K": K.astype(np.float64)}
+    return cameras
+
+
+def update_image_data_from_ba_results(image_data, optimized_cameras):
+    """Write optimised R, t back into the image_data tuples, in place (BundleAdjustment.py:298-306)."""
+    for img_id, cam in optimized_cameras.items():
+        if img_id in image_data:
+            entry = list(image_data[img_id])
+            entry[0] = cam["R"].astype(np.float64)
+            entry[1] = cam["t"].astype(np.float64)
+            image_data[img_id] = tuple(entry)
+    return image_data
+
+
+def inter_ba(image_data, all_points_3D, visited_ids,
+             ba_interval=10, verbose=True):
+    """Intermediate BA every ``ba_interval`` registered images: huber, f_scale 1.5, max_nfev 150
+    (BundleAdjustment.py:309-350).  Returns (points, image_data, ran_ok)."""
+    if len(visited_ids) % ba_interval != 0 or len(visited_ids) < 3:
+        return all_points_3D, image_data, False
+
+    if verbose:
+        print(f"\n{'=' * 50}")
+        print(f"RUNNING BUNDLE ADJUSTMENT - {len(visited_ids)} images processed")
+        print(f"{'=' * 50}")
+
+    cameras = prepare_cameras_from_image_data(image_data, visited_ids)
+    observations = prepare_observations_from_image_data(image_data, visited_ids, all_points_3D)
+
+    if len(cameras) < 3 or len(all_points_3D) < 10 or len(observations) < 20:
+        if verbose:
+            print("[BA] Insufficient data for BA")
+        return all_points_3D, image_data, False
+
+    optimized_cameras, optimized_points, success = global_bundle_adjustment(
+        cameras, all_points_3D, observations, visited_ids,
+        robust_loss='huber', loss_f_scale=1.5, max_nfev=150, verbose=verbose)
+
+    if success:
+        image_data = update_image_data_from_ba_results(image_data, optimized_cameras)
+        if verbose:
+            print(f"[BA] Successfully optimized {len(optimized_cameras)} cameras and {len(optimized_points)} points")
+        return optimized_points, image_data, True
+    if verbose:
+        print("[BA] Bundle adjustment failed")
+    return all_points_3D, image_data, False
+
+
+def final_ba(image_data, all_points_3D, visited_ids, verbose=True):
+    """Final BA over everything: huber, f_scale 1.0, max_nfev 300 (BundleAdjustment.py:353-385).
+    Returns (points, image_data, ok)."""
+    if verbose:
+        print(f"\n{'=' * 60}")
+        print("RUNNING FINAL BUNDLE ADJUSTMENT")
+        print(f"{'=' * 60}")
+
+    cameras = prepare_cameras_from_image_data(image_data, visited_ids)
+    observations = prepare_observations_from_image_data(image_data, visited_ids, all_points_3D)
+
+    optimized_cameras, optimized_points, success = global_bundle_adjustment(
+        cameras, all_points_3D, observations, visited_ids,
+        robust_loss='huber', loss_f_scale=1.0, max_nfev=300, verbose=verbose)
+
+    if success:
+        image_data = update_image_data_from_ba_results(image_data, optimized_cameras)
+        if verbose:
+            print("[BA] Final BA completed successfully!")
+        return optimized_points, image_data, True
+    if verbose:
+        print("[BA] Final BA failed")
+    return all_points_3D, image_data, False
+
+
+def compute_ba_reprojection_errors(image_data, all_points_3D, visited_ids):
+    """Mean L2 reprojection error per registered camera, ``{img_id: error}``
+    (BundleAdjustment.py:388-423 with utils.ReprojectionError, utils.py:271-276: full K product).
+    One HIP launch for all cameras instead of one NumPy evaluation per camera."""
+    ids, poses, Ks = [], [], []
+    obs_cam, obs_pt, obs_xy = [], [], []
+    n_points = len(all_points_3D)
+    for img_id in visited_ids:
+        if img_id not in image_data:
+            continue
+        cam_data = image_data[img_id]
+        if len(cam_data) < 6:
+            continue
+        kp = cam_data[5]
+        entries = list(_valid_track_entries(cam_data, n_points))
+        if not entries:
+            continue
+        ci = len(ids)
+        ids.append(img_id)
+        poses.append(np.concatenate([matrix_to_rvec(cam_data[0]), np.asarray(cam_data[1], dtype=np.float64).reshape(3)]))
+        Ks.append(np.asarray(cam_data[2], dtype=np.float64).reshape(9))
+        for kp_idx, point_idx in entries:
+            obs_cam.append(ci)
+            obs_pt.append(point_idx)
+            obs_xy.append(kp[kp_idx].pt)
+    if not ids:
+        return {}
+    points = np.array([[p[0], p[1], p[2]] for p in all_points_3D], dtype=np.float64).reshape(-1, 3)
+    Ks = np.array(Ks)
+    intr = np.stack([Ks[:, 0], Ks[:, 4], Ks[:, 2], Ks[:, 5]], axis=1)
+    arr = _capi.Arrays(np.array(poses), intr, np.zeros(len(ids), np.uint8), points, obs_cam, obs_pt,
+                       np.array(obs_xy, dtype=np.float64))
+    err = _capi.eval_reprojection_errors(arr, Ks)
+    return {img_id: float(err[i]) for i, img_id in enumerate(ids)}

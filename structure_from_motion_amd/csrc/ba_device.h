@@ -1,0 +1,160 @@
+// Device-side camera arithmetic shared by every kernel (gfx950, fp64).
+//
+// Objective being reproduced:
+//   residual  = cv2.projectPoints(X, rvec, tvec, K, None) - pixel      BundleAdjustment.py:142-145
+//   cost      = 0.5 * sum_i fs^2 rho((f_i/fs)^2) per scalar component  scipy _lsq/least_squares.py:220-227
+// The reference differentiates the residual closure by 2-point differences over its sparsity
+// pattern (BundleAdjustment.py:154-198, :212); here the same non-zero 2x6 / 2x3 blocks are
+// analytic, with the true derivative of the exponential map because scipy updates rvec
+// additively (scipy _lsq/trf.py:497).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define BA_CAM_AUX 26  // doubles per camera: R[9] Jl[9] t[3] fx fy cx cy pad
+#define BA_D_MIN 1e-6  // clamp of the Marquardt scaling diag(J^T W J)
+#define BA_D_MAX 1e32
+
+namespace ba {
+
+struct CamAux {
+    double R[9];   // rotation, row-major
+    double Jl[9];  // left Jacobian of SO(3): d(R X)/d rvec = -[R X]x Jl
+    double t[3];
+    double fx, fy, cx, cy;
+};
+
+// Per-camera precomputation (hoisted out of the per-observation loop: fp64 sincos is long).
+__device__ __forceinline__ void cam_aux_from_pose(const double *__restrict__ pose, const double *__restrict__ intr,
+                                                  double *__restrict__ out) {
+    const double rx = pose[0], ry = pose[1], rz = pose[2];
+    const double s = rx * rx + ry * ry + rz * rz;
+    const double th = sqrt(s);
+    double R[9];
+    if (th < 2.220446049250313e-16) {  // cv2.Rodrigues: theta < DBL_EPSILON -> identity
+        R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
+    } else {
+        double sn, c;
+        sincos(th, &sn, &c);
+        const double c1 = 1.0 - c, it = 1.0 / th;
+        const double kx = rx * it, ky = ry * it, kz = rz * it;
+        R[0] = c + c1 * kx * kx;       R[1] = c1 * kx * ky - sn * kz;  R[2] = c1 * kx * kz + sn * ky;
+        R[3] = c1 * kx * ky + sn * kz; R[4] = c + c1 * ky * ky;        R[5] = c1 * ky * kz - sn * kx;
+        R[6] = c1 * kx * kz - sn * ky; R[7] = c1 * ky * kz + sn * kx;  R[8] = c + c1 * kz * kz;
+    }
+    double b, c3;  // (1-cos)/th^2, (th - sin)/th^3
+    if (s < 1e-2) {
+        b = 0.5 + s * (-1.0 / 24 + s * (1.0 / 720 + s * (-1.0 / 40320 + s * (1.0 / 3628800 - s * (1.0 / 479001600)))));
+        c3 = 1.0 / 6 + s * (-1.0 / 120 + s * (1.0 / 5040 + s * (-1.0 / 362880 + s * (1.0 / 39916800 - s * (1.0 / 6227020800.0)))));
+    } else {
+        b = (1.0 - cos(th)) / s;
+        c3 = (th - sin(th)) / (s * th);
+    }
+    // Jl = I + b [r]x + c3 [r]x^2,   [r]x^2 = r r^T - s I
+    double Jl[9];
+    Jl[0] = 1.0 + c3 * (rx * rx - s); Jl[1] = -b * rz + c3 * rx * ry;   Jl[2] = b * ry + c3 * rx * rz;
+    Jl[3] = b * rz + c3 * rx * ry;    Jl[4] = 1.0 + c3 * (ry * ry - s); Jl[5] = -b * rx + c3 * ry * rz;
+    Jl[6] = -b * ry + c3 * rx * rz;   Jl[7] = b * rx + c3 * ry * rz;    Jl[8] = 1.0 + c3 * (rz * rz - s);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { out[i] = R[i]; out[9 + i] = Jl[i]; }
+    out[18] = pose[3]; out[19] = pose[4]; out[20] = pose[5];
+    out[21] = intr[0]; out[22] = intr[1]; out[23] = intr[2]; out[24] = intr[3];
+    out[25] = 0.0;
+}
+
+__device__ __forceinline__ void load_aux(const double *__restrict__ aux, int cam, CamAux &c) {
+    const double2 *p = reinterpret_cast<const double2 *>(aux + (size_t)cam * BA_CAM_AUX);
+    double2 v[13];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) v[i] = p[i];
+    c.R[0] = v[0].x; c.R[1] = v[0].y; c.R[2] = v[1].x; c.R[3] = v[1].y; c.R[4] = v[2].x; c.R[5] = v[2].y;
+    c.R[6] = v[3].x; c.R[7] = v[3].y; c.R[8] = v[4].x;
+    c.Jl[0] = v[4].y; c.Jl[1] = v[5].x; c.Jl[2] = v[5].y; c.Jl[3] = v[6].x; c.Jl[4] = v[6].y; c.Jl[5] = v[7].x;
+    c.Jl[6] = v[7].y; c.Jl[7] = v[8].x; c.Jl[8] = v[8].y;
+    c.t[0] = v[9].x; c.t[1] = v[9].y; c.t[2] = v[10].x;
+    c.fx = v[10].y; c.fy = v[11].x; c.cx = v[11].y; c.cy = v[12].x;
+}
+
+// Projection only (trial-cost and evaluation kernels): R, t, intrinsics.
+__device__ __forceinline__ void project_only(const double *__restrict__ aux, int cam, double X0, double X1, double X2,
+                                             double &u, double &v) {
+    const double2 *p = reinterpret_cast<const double2 *>(aux + (size_t)cam * BA_CAM_AUX);
+    const double2 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3], a4 = p[4], a9 = p[9], a10 = p[10], a11 = p[11], a12 = p[12];
+    const double x = a0.x * X0 + a0.y * X1 + a1.x * X2 + a9.x;
+    const double y = a1.y * X0 + a2.x * X1 + a2.y * X2 + a9.y;
+    const double z = a3.x * X0 + a3.y * X1 + a4.x * X2 + a10.x;
+    const double iz = (z != 0.0) ? 1.0 / z : 1.0;  // cv2.projectPoints: z == 0 -> 1
+    u = a10.y * (x * iz) + a11.y;
+    v = a11.x * (y * iz) + a12.x;
+}
+
+// rho(z), rho'(z) per scalar residual component, z = (f/fs)^2 (scipy _lsq/least_squares.py:169-205).
+__device__ __forceinline__ void loss_eval(int kind, double z, double &rho, double &w) {
+    switch (kind) {
+        case 0: rho = z; w = 1.0; break;                                             // linear
+        case 1: { double t = sqrt(1.0 + z); rho = 2.0 * (t - 1.0); w = 1.0 / t; } break;  // soft_l1
+        case 2:                                                                      // huber
+            if (z <= 1.0) { rho = z; w = 1.0; }
+            else { double t = sqrt(z); rho = 2.0 * t - 1.0; w = 1.0 / t; }
+            break;
+        case 3: rho = log1p(z); w = 1.0 / (1.0 + z); break;                          // cauchy
+        default: rho = atan(z); w = 1.0 / (1.0 + z * z); break;                      // arctan
+    }
+}
+
+struct ObsLin {
+    double r[2];      // residual (du, dv)
+    double w[2];      // IRLS weights rho'
+    double rho_sum;   // rho(z_u) + rho(z_v)
+    double Jc[2][6];  // d(du,dv)/d(rvec, t)
+    double Jp[2][3];  // d(du,dv)/dX
+};
+
+// Residual + analytic Jacobian blocks of one observation.
+__device__ __forceinline__ void linearize(const CamAux &c, double X0, double X1, double X2, double uo, double vo,
+                                          int loss, double inv_fs2, ObsLin &o) {
+    const double Y0 = c.R[0] * X0 + c.R[1] * X1 + c.R[2] * X2;
+    const double Y1 = c.R[3] * X0 + c.R[4] * X1 + c.R[5] * X2;
+    const double Y2 = c.R[6] * X0 + c.R[7] * X1 + c.R[8] * X2;
+    const double x = Y0 + c.t[0], y = Y1 + c.t[1], z = Y2 + c.t[2];
+    const bool nz = (z != 0.0);
+    const double iz = nz ? 1.0 / z : 1.0;
+    const double xn = x * iz, yn = y * iz;
+    o.r[0] = c.fx * xn + c.cx - uo;
+    o.r[1] = c.fy * yn + c.cy - vo;
+    const double a = c.fx * iz, b = c.fy * iz;
+    const double p02 = nz ? -a * xn : 0.0, p12 = nz ? -b * yn : 0.0;
+    // translation block = P
+    o.Jc[0][3] = a;   o.Jc[0][4] = 0.0; o.Jc[0][5] = p02;
+    o.Jc[1][3] = 0.0; o.Jc[1][4] = b;   o.Jc[1][5] = p12;
+    // point block = P R
+    o.Jp[0][0] = a * c.R[0] + p02 * c.R[6]; o.Jp[0][1] = a * c.R[1] + p02 * c.R[7]; o.Jp[0][2] = a * c.R[2] + p02 * c.R[8];
+    o.Jp[1][0] = b * c.R[3] + p12 * c.R[6]; o.Jp[1][1] = b * c.R[4] + p12 * c.R[7]; o.Jp[1][2] = b * c.R[5] + p12 * c.R[8];
+    // rotation block = (P * -[Y]x) Jl
+    const double q00 = p02 * Y1, q01 = a * Y2 - p02 * Y0, q02 = -a * Y1;
+    const double q10 = -b * Y2 + p12 * Y1, q11 = -p12 * Y0, q12 = b * Y0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        o.Jc[0][j] = q00 * c.Jl[j] + q01 * c.Jl[3 + j] + q02 * c.Jl[6 + j];
+        o.Jc[1][j] = q10 * c.Jl[j] + q11 * c.Jl[3 + j] + q12 * c.Jl[6 + j];
+    }
+    double rho0, rho1;
+    loss_eval(loss, o.r[0] * o.r[0] * inv_fs2, rho0, o.w[0]);
+    loss_eval(loss, o.r[1] * o.r[1] * inv_fs2, rho1, o.w[1]);
+    o.rho_sum = rho0 + rho1;
+}
+
+// index of (i,j), i<=j, in a row-major packed upper triangle of a 6x6
+__host__ __device__ __forceinline__ constexpr int ut6(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+    return v;
+}
+
+}  // namespace ba

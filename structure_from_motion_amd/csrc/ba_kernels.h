@@ -1,0 +1,721 @@
+// HIP kernels of the bundle-adjustment engine (gfx950 / CDNA4, wave64, fp64).
+// Included once by ba_engine.hip.
+//
+//   k_cam_prep        per camera: rotation matrix + SO(3) left Jacobian            (tiny)
+//   k_build           FUSED per chunk of points: residual, analytic Jacobian blocks, robust
+//                     weights, per-point V / g_p in LDS, 3x3 Cholesky in registers, per-camera
+//                     U / g_c and Schur-complement blocks accumulated in LDS tiles, one flush of
+//                     the tiles to HBM per chunk.              HBM-bound: 40 B/obs + 96 B/point
+//   k_finalize        per free camera: damping, diagonal block, block-Jacobi inverse (tiny)
+//   k_pcg_*           block-Jacobi preconditioned CG on the block-sparse reduced camera system
+//   k_cam_update      trial camera poses
+//   k_backsub         FUSED per chunk: back-substitution of the point steps, model (predicted)
+//                     reduction, trial points, trial cost
+//   k_reduce_* / k_decide   deterministic reductions + the LM accept / damping logic on device
+//   k_eval_*          building blocks in the caller's observation order (parity probes)
+#pragma once
+#include "ba_device.h"
+#include "ba_symbolic.h"
+
+namespace ba {
+
+// ------------------------------------------------------------------ LM state kept on device
+struct LmState {
+    double lambda, nu;
+    double F;         // cost at the current state
+    double F_trial;   // cost at the trial state
+    double pred;      // model reduction of the last step
+    double rho;       // gain ratio
+    double step_norm, x_norm;
+    double gmax;      // ||g||_inf at the current state
+    double dF;
+    int accept, status, iter, n_accept;
+    int terminate, pad0, pad1, pad2;
+};
+
+struct BuildArgs {
+    const double *aux;      // [n_cams * BA_CAM_AUX]
+    const double *points;   // [n_points*3] internal order
+    const int *o_cam;
+    const int *o_pt;
+    const short *o_lcam;
+    const double *o_xy;
+    const int *cam_free;
+    const int *ck_obs, *ck_pt, *ck_cam, *ck_cam_list, *ck_pair, *ck_pair_slot;
+    const long long *ck_pe;
+    const unsigned *pair_entries;
+    double *S, *U, *gc, *gred;      // reduced-system accumulators (zeroed before the launch)
+    double *pt_linv, *pt_u;         // [n_pts_obs*6], [n_pts_obs*3]
+    double *ck_cost, *ck_gmax;      // per-chunk partials
+    double *dbg_v, *dbg_gp;         // optional [n_pts_obs*6], [n_pts_obs*3]
+    const LmState *state;           // lambda is read from here
+    int loss;
+    double inv_fs2, half_fs2;
+};
+
+__global__ void k_cam_prep(int n_cams, const double *__restrict__ pose, const double *__restrict__ intr,
+                           double *__restrict__ aux) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n_cams) cam_aux_from_pose(pose + 6 * (size_t)c, intr + 4 * (size_t)c, aux + (size_t)c * BA_CAM_AUX);
+}
+
+// sum / max of one value per thread over a 256-thread block; result valid in thread 0
+__device__ __forceinline__ double block_sum256(double v, double *scratch) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    return scratch[0] + scratch[1] + scratch[2] + scratch[3];
+}
+__device__ __forceinline__ double block_max256(double v, double *scratch) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    return fmax(fmax(scratch[0], scratch[1]), fmax(scratch[2], scratch[3]));
+}
+
+__global__ __launch_bounds__(CHUNK_OBS) void k_build(const BuildArgs A) {
+    __shared__ double sT[CHUNK_OBS * 18];     // T = W L^-T per observation (6x3)
+    __shared__ double sP[CHUNK_PTS * 9];      // per point: V(6) g_p(3), then L^-1(6) u(3)
+    __shared__ double sC[CHUNK_CAMS * 33];    // per local camera: U(21) g_c(6) g_red(6)
+    __shared__ double sS[CHUNK_PAIRS * 36];   // per local camera pair: -sum T_i T_j^T
+    __shared__ double sRed[4];
+
+    const int ck = blockIdx.x, tid = threadIdx.x;
+    const int ob = A.ck_obs[ck], nobs = A.ck_obs[ck + 1] - ob;
+    const int pb = A.ck_pt[ck], npts = A.ck_pt[ck + 1] - pb;
+    const int cb = A.ck_cam[ck], ncam = A.ck_cam[ck + 1] - cb;
+    const int qb = A.ck_pair[ck], npair = A.ck_pair[ck + 1] - qb;
+    const int ntile = npair < CHUNK_PAIRS ? npair : CHUNK_PAIRS;
+    const double lam = A.state->lambda;
+
+    for (int i = tid; i < npts * 9; i += CHUNK_OBS) sP[i] = 0.0;
+    for (int i = tid; i < ncam * 33; i += CHUNK_OBS) sC[i] = 0.0;
+    for (int i = tid; i < ntile * 36; i += CHUNK_OBS) sS[i] = 0.0;
+    __syncthreads();
+
+    // ---- phase 1: one observation per lane ------------------------------------------------
+    double W[18];
+    int lp = 0, lc = -2, fcam = -1;
+    double cost_loc = 0.0;
+    const bool act = tid < nobs;
+    if (act) {
+        const int o = ob + tid;
+        const int cam = A.o_cam[o];
+        const int p = A.o_pt[o];
+        lp = p - pb;
+        lc = A.o_lcam[o];
+        CamAux ca;
+        load_aux(A.aux, cam, ca);
+        const double X0 = A.points[3 * (size_t)p], X1 = A.points[3 * (size_t)p + 1], X2 = A.points[3 * (size_t)p + 2];
+        const double2 xy = reinterpret_cast<const double2 *>(A.o_xy)[o];
+        ObsLin L;
+        linearize(ca, X0, X1, X2, xy.x, xy.y, A.loss, A.inv_fs2, L);
+        cost_loc = A.half_fs2 * L.rho_sum;
+        double wJp[2][3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { wJp[0][j] = L.w[0] * L.Jp[0][j]; wJp[1][j] = L.w[1] * L.Jp[1][j]; }
+        double *vp = &sP[lp * 9];
+        atomicAdd(&vp[0], wJp[0][0] * L.Jp[0][0] + wJp[1][0] * L.Jp[1][0]);
+        atomicAdd(&vp[1], wJp[0][0] * L.Jp[0][1] + wJp[1][0] * L.Jp[1][1]);
+        atomicAdd(&vp[2], wJp[0][0] * L.Jp[0][2] + wJp[1][0] * L.Jp[1][2]);
+        atomicAdd(&vp[3], wJp[0][1] * L.Jp[0][1] + wJp[1][1] * L.Jp[1][1]);
+        atomicAdd(&vp[4], wJp[0][1] * L.Jp[0][2] + wJp[1][1] * L.Jp[1][2]);
+        atomicAdd(&vp[5], wJp[0][2] * L.Jp[0][2] + wJp[1][2] * L.Jp[1][2]);
+        atomicAdd(&vp[6], wJp[0][0] * L.r[0] + wJp[1][0] * L.r[1]);
+        atomicAdd(&vp[7], wJp[0][1] * L.r[0] + wJp[1][1] * L.r[1]);
+        atomicAdd(&vp[8], wJp[0][2] * L.r[0] + wJp[1][2] * L.r[1]);
+        if (lc != -2) {  // free camera
+            double wJc[2][6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { wJc[0][i] = L.w[0] * L.Jc[0][i]; wJc[1][i] = L.w[1] * L.Jc[1][i]; }
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) W[i * 3 + j] = wJc[0][i] * L.Jp[0][j] + wJc[1][i] * L.Jp[1][j];
+            if (lc >= 0) {
+                double *cp = &sC[lc * 33];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+#pragma unroll
+                    for (int j = i; j < 6; ++j) atomicAdd(&cp[ut6(i, j)], wJc[0][i] * L.Jc[0][j] + wJc[1][i] * L.Jc[1][j]);
+                    atomicAdd(&cp[21 + i], wJc[0][i] * L.r[0] + wJc[1][i] * L.r[1]);
+                }
+            } else {  // camera without an LDS tile in this chunk: straight to HBM
+                fcam = A.cam_free[cam];
+                double *up = &A.U[(size_t)fcam * 21], *gp = &A.gc[(size_t)fcam * 6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+#pragma unroll
+                    for (int j = i; j < 6; ++j) atomicAdd(&up[ut6(i, j)], wJc[0][i] * L.Jc[0][j] + wJc[1][i] * L.Jc[1][j]);
+                    atomicAdd(&gp[i], wJc[0][i] * L.r[0] + wJc[1][i] * L.r[1]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2a: one point per lane: damp, 3x3 Cholesky, inverse factor in registers ------
+    double gmax_loc = 0.0;
+    if (tid < npts) {
+        double *vp = &sP[tid * 9];
+        const double v00 = vp[0], v01 = vp[1], v02 = vp[2], v11 = vp[3], v12 = vp[4], v22 = vp[5];
+        const double g0 = vp[6], g1 = vp[7], g2 = vp[8];
+        gmax_loc = fmax(fabs(g0), fmax(fabs(g1), fabs(g2)));
+        if (A.dbg_v) {
+            double *dv = &A.dbg_v[(size_t)(pb + tid) * 6];
+            dv[0] = v00; dv[1] = v01; dv[2] = v02; dv[3] = v11; dv[4] = v12; dv[5] = v22;
+            double *dg = &A.dbg_gp[(size_t)(pb + tid) * 3];
+            dg[0] = g0; dg[1] = g1; dg[2] = g2;
+        }
+        const double a00 = v00 + lam * fmin(fmax(v00, BA_D_MIN), BA_D_MAX);
+        const double a11 = v11 + lam * fmin(fmax(v11, BA_D_MIN), BA_D_MAX);
+        const double a22 = v22 + lam * fmin(fmax(v22, BA_D_MIN), BA_D_MAX);
+        const double l00 = sqrt(a00);
+        const double i00 = 1.0 / l00;
+        const double l10 = v01 * i00, l20 = v02 * i00;
+        // (V + lambda D is positive definite; the floors only guard the rounding of rank-deficient V)
+        const double l11 = sqrt(fmax(a11 - l10 * l10, 1e-15 * a11));
+        const double i11 = 1.0 / l11;
+        const double l21 = (v12 - l20 * l10) * i11;
+        const double l22 = sqrt(fmax(a22 - l20 * l20 - l21 * l21, 1e-15 * a22));
+        const double i22 = 1.0 / l22;
+        const double i10 = -l10 * i00 * i11;
+        const double i21 = -l21 * i11 * i22;
+        const double i20 = -(l20 * i00 + l21 * i10) * i22;
+        const double u0 = i00 * g0, u1 = i10 * g0 + i11 * g1, u2 = i20 * g0 + i21 * g1 + i22 * g2;
+        vp[0] = i00; vp[1] = i10; vp[2] = i11; vp[3] = i20; vp[4] = i21; vp[5] = i22;
+        vp[6] = u0; vp[7] = u1; vp[8] = u2;
+        double *gl = &A.pt_linv[(size_t)(pb + tid) * 6];
+        gl[0] = i00; gl[1] = i10; gl[2] = i11; gl[3] = i20; gl[4] = i21; gl[5] = i22;
+        double *gu = &A.pt_u[(size_t)(pb + tid) * 3];
+        gu[0] = u0; gu[1] = u1; gu[2] = u2;
+    }
+    {
+        const double cs = block_sum256(cost_loc, sRed);
+        const double gm = block_max256(gmax_loc, sRed);
+        if (tid == 0) { A.ck_cost[ck] = cs; A.ck_gmax[ck] = gm; }
+    }
+    __syncthreads();
+
+    // ---- phase 2b: T = W L^-T, reduced gradient -------------------------------------------
+    if (act && lc != -2) {
+        const double *vp = &sP[lp * 9];
+        const double i00 = vp[0], i10 = vp[1], i11 = vp[2], i20 = vp[3], i21 = vp[4], i22 = vp[5];
+        const double u0 = vp[6], u1 = vp[7], u2 = vp[8];
+        double *tp = &sT[tid * 18];
+        double gr[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const double t0 = W[i * 3] * i00;
+            const double t1 = W[i * 3] * i10 + W[i * 3 + 1] * i11;
+            const double t2 = W[i * 3] * i20 + W[i * 3 + 1] * i21 + W[i * 3 + 2] * i22;
+            tp[i * 3] = t0; tp[i * 3 + 1] = t1; tp[i * 3 + 2] = t2;
+            gr[i] = -(t0 * u0 + t1 * u1 + t2 * u2);
+        }
+        if (lc >= 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) atomicAdd(&sC[lc * 33 + 27 + i], gr[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) atomicAdd(&A.gred[(size_t)fcam * 6 + i], gr[i]);
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: Schur-complement blocks, lanes over matrix elements -----------------------
+    {
+        const long long peb = A.ck_pe[ck];
+        const int nelem = (int)(A.ck_pe[ck + 1] - peb) * 36;
+        for (int e = tid; e < nelem; e += CHUNK_OBS) {
+            const int q = e / 36, ab = e - q * 36, a = ab / 6, b = ab - a * 6;
+            const unsigned ent = A.pair_entries[peb + q];
+            const int oi = ent & 255u, oj = (ent >> 8) & 255u, lpi = ent >> 16;
+            const double *ti = &sT[oi * 18 + a * 3], *tj = &sT[oj * 18 + b * 3];
+            const double val = -(ti[0] * tj[0] + ti[1] * tj[1] + ti[2] * tj[2]);
+            if (lpi < CHUNK_PAIRS) atomicAdd(&sS[lpi * 36 + ab], val);
+            else atomicAdd(&A.S[(size_t)A.ck_pair_slot[qb + lpi] * 36 + ab], val);
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 4: one flush of the LDS tiles per chunk ----------------------------------------
+    for (int i = tid; i < ncam * 33; i += CHUNK_OBS) {
+        const int l = i / 33, k = i - l * 33;
+        const size_t f = (size_t)A.ck_cam_list[cb + l];
+        const double v = sC[i];
+        if (k < 21) atomicAdd(&A.U[f * 21 + k], v);
+        else if (k < 27) atomicAdd(&A.gc[f * 6 + (k - 21)], v);
+        else atomicAdd(&A.gred[f * 6 + (k - 27)], v);
+    }
+    for (int i = tid; i < ntile * 36; i += CHUNK_OBS) {
+        const int l = i / 36, k = i - l * 36;
+        atomicAdd(&A.S[(size_t)A.ck_pair_slot[qb + l] * 36 + k], sS[i]);
+    }
+}
+
+// ------------------------------------------------------------------ finalize the reduced system
+// 6x6 SPD inverse by Cholesky in registers; returns false if not positive definite.
+__device__ __forceinline__ bool spd6_inverse(const double *__restrict__ Ain, double *__restrict__ out) {
+    double L[6][6];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double d = Ain[j * 6 + j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+        if (!(d > 0.0)) ok = false;
+        const double ljj = sqrt(d);
+        L[j][j] = ljj;
+        const double inv = 1.0 / ljj;
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+            double s = Ain[i * 6 + j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
+            L[i][j] = s * inv;
+        }
+    }
+    if (!ok) return false;
+    double Li[6][6];  // inverse of L (lower)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        Li[j][j] = 1.0 / L[j][j];
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = j; k < i; ++k) s -= L[i][k] * Li[k][j];
+            Li[i][j] = s / L[i][i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = i; k < 6; ++k) s += Li[k][i] * Li[k][j];
+            out[i * 6 + j] = s;
+            out[j * 6 + i] = s;
+        }
+    return true;
+}
+
+__global__ void k_finalize(int nf, const double *__restrict__ U, const double *__restrict__ gc, double *__restrict__ S,
+                           const int *__restrict__ diag_slot, double *__restrict__ Minv, double *__restrict__ cam_gmax,
+                           const LmState *__restrict__ st) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nf) return;
+    const double lam = st->lambda;
+    double *blk = &S[(size_t)diag_slot[f] * 36];
+    const double *u = &U[(size_t)f * 21];
+    double A[36];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i; j < 6; ++j) {
+            double v = u[ut6(i, j)];
+            if (i == j) v += lam * fmin(fmax(v, BA_D_MIN), BA_D_MAX);
+            const double a = blk[i * 6 + j] + v;
+            const double bsym = (i == j) ? a : blk[j * 6 + i] + v;
+            // the Schur part is symmetric up to the rounding of the atomics; keep both halves as accumulated
+            A[i * 6 + j] = a;
+            A[j * 6 + i] = bsym;
+        }
+#pragma unroll
+    for (int k = 0; k < 36; ++k) blk[k] = A[k];
+    double Ms[36];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) Ms[i * 6 + j] = 0.5 * (A[i * 6 + j] + A[j * 6 + i]);
+    double Mi[36];
+    if (!spd6_inverse(Ms, Mi)) {
+#pragma unroll
+        for (int k = 0; k < 36; ++k) Mi[k] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Mi[i * 6 + i] = 1.0 / fmax(fabs(Ms[i * 6 + i]), 1e-300);
+    }
+#pragma unroll
+    for (int k = 0; k < 36; ++k) Minv[(size_t)f * 36 + k] = Mi[k];
+    double gm = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) gm = fmax(gm, fabs(gc[(size_t)f * 6 + i]));
+    cam_gmax[f] = gm;
+}
+
+// ------------------------------------------------------------------ PCG on S x = -g_red
+// scalars: rz[3] (rotating), pq[2] (alternating), rn[3] (rotating), bnorm2, done(as double), iters(as double)
+struct PcgScalars {
+    double rz[3], pq[2], rn[3], bnorm2, done, iters, pad;
+};
+
+__global__ void k_pcg_init(int n, const double *__restrict__ gred, const double *__restrict__ Minv, double *__restrict__ x,
+                           double *__restrict__ r, double *__restrict__ z, double *__restrict__ p, PcgScalars *sc) {
+    __shared__ double red[4];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double rz = 0.0, bb = 0.0;
+    if (i < n) {
+        const int f = i / 6, a = i - f * 6;
+        double rv[6];
+#pragma unroll
+        for (int b = 0; b < 6; ++b) rv[b] = -gred[f * 6 + b];
+        double zz = 0.0;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) zz += Minv[(size_t)f * 36 + a * 6 + b] * rv[b];
+        x[i] = 0.0; r[i] = rv[a]; z[i] = zz; p[i] = zz;
+        rz = rv[a] * zz; bb = rv[a] * rv[a];
+    }
+    rz = block_sum256(rz, red);
+    bb = block_sum256(bb, red);
+    if (threadIdx.x == 0) { atomicAdd(&sc->rz[0], rz); atomicAdd(&sc->bnorm2, bb); }
+}
+
+__global__ void k_pcg_spmv(int n, int it, const int *__restrict__ bsr_row, const int *__restrict__ bsr_col,
+                           const int *__restrict__ bsr_src, const double *__restrict__ S, const double *__restrict__ p,
+                           double *__restrict__ q, PcgScalars *sc) {
+    __shared__ double red[4];
+    if (sc->done != 0.0) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double pq = 0.0;
+    if (i < n) {
+        const int f = i / 6, a = i - f * 6;
+        double acc = 0.0;
+        for (int k = bsr_row[f]; k < bsr_row[f + 1]; ++k) {
+            const int src = bsr_src[k];
+            const double *blk = &S[(size_t)(src & 0x7fffffff) * 36];
+            const double *pj = &p[(size_t)bsr_col[k] * 6];
+            if (src >= 0) {
+#pragma unroll
+                for (int b = 0; b < 6; ++b) acc += blk[a * 6 + b] * pj[b];
+            } else {
+#pragma unroll
+                for (int b = 0; b < 6; ++b) acc += blk[b * 6 + a] * pj[b];
+            }
+        }
+        q[i] = acc;
+        pq = acc * p[i];
+    }
+    pq = block_sum256(pq, red);
+    if (threadIdx.x == 0) atomicAdd(&sc->pq[it & 1], pq);
+}
+
+__global__ void k_pcg_update(int n, int it, const double *__restrict__ Minv, const double *__restrict__ p,
+                             const double *__restrict__ q, double *__restrict__ x, double *__restrict__ r,
+                             double *__restrict__ z, PcgScalars *sc) {
+    __shared__ double red[4];
+    if (sc->done != 0.0) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const double pqv = sc->pq[it & 1];
+    const double alpha = (pqv > 0.0) ? sc->rz[it % 3] / pqv : 0.0;
+    double rz = 0.0, rn = 0.0;
+    if (i < n) {
+        const int f = i / 6, a = i - f * 6;
+        double rv[6];
+#pragma unroll
+        for (int b = 0; b < 6; ++b) rv[b] = r[f * 6 + b] - alpha * q[f * 6 + b];
+        double zz = 0.0;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) zz += Minv[(size_t)f * 36 + a * 6 + b] * rv[b];
+        x[i] += alpha * p[i];
+        z[i] = zz;
+        rz = rv[a] * zz; rn = rv[a] * rv[a];
+        // r[i] is written by k_pcg_direction (other lanes of this camera still read the old r here)
+    }
+    rz = block_sum256(rz, red);
+    rn = block_sum256(rn, red);
+    if (threadIdx.x == 0) { atomicAdd(&sc->rz[(it + 1) % 3], rz); atomicAdd(&sc->rn[(it + 1) % 3], rn); }
+}
+
+__global__ void k_pcg_direction(int n, int it, double tol2, const double *__restrict__ q, const double *__restrict__ z,
+                                double *__restrict__ r, double *__restrict__ p, PcgScalars *sc) {
+    if (sc->done != 0.0) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const double rz_old = sc->rz[it % 3], rz_new = sc->rz[(it + 1) % 3];
+    const double pqv = sc->pq[it & 1];
+    const double alpha = (pqv > 0.0) ? rz_old / pqv : 0.0;
+    const double beta = (rz_old > 0.0) ? rz_new / rz_old : 0.0;
+    const double rn = sc->rn[(it + 1) % 3];
+    const double bn = sc->bnorm2;
+    if (i < n) {
+        r[i] -= alpha * q[i];
+        p[i] = z[i] + beta * p[i];
+    }
+    if (i == 0) {
+        // slots nobody reads in this launch
+        sc->rz[(it + 2) % 3] = 0.0;
+        sc->rn[(it + 2) % 3] = 0.0;
+        sc->pq[(it + 1) & 1] = 0.0;
+        sc->iters = it + 1;
+    }
+    // every block evaluates the same test; the flag only matters for LATER launches
+    if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) {
+        if (!(rn > tol2 * bn) || !(pqv > 0.0)) sc->done = 1.0;
+    }
+}
+
+// ------------------------------------------------------------------ trial cameras
+__global__ void k_cam_update(int n_cams, const int *__restrict__ cam_free, const double *__restrict__ pose,
+                             const double *__restrict__ intr, const double *__restrict__ dx, double *__restrict__ pose_t,
+                             double *__restrict__ aux_t, double *__restrict__ cam_part) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cams) return;
+    const int f = cam_free[c];
+    double ps[6], d2 = 0.0, x2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const double v = pose[6 * (size_t)c + i];
+        double d = 0.0;
+        if (f >= 0) { d = dx[(size_t)f * 6 + i]; d2 += d * d; x2 += v * v; }
+        ps[i] = v + d;
+        pose_t[6 * (size_t)c + i] = ps[i];
+    }
+    cam_aux_from_pose(ps, intr + 4 * (size_t)c, aux_t + (size_t)c * BA_CAM_AUX);
+    cam_part[2 * (size_t)c] = d2;
+    cam_part[2 * (size_t)c + 1] = x2;
+}
+
+// ------------------------------------------------------------------ back-substitution + trial cost
+struct BacksubArgs {
+    const double *aux, *aux_t;
+    const double *points;
+    double *points_t;
+    const int *o_cam, *o_pt;
+    const double *o_xy;
+    const int *cam_free;
+    const int *ck_obs, *ck_pt;
+    const double *dx;               // camera step [n_free*6]
+    const double *pt_linv, *pt_u;
+    double *ck_part;                // [n_chunks*4]: pred, F_trial, |dp|^2, |x_p|^2
+    int loss;
+    double inv_fs2, half_fs2;
+};
+
+__global__ __launch_bounds__(CHUNK_OBS) void k_backsub(const BacksubArgs A) {
+    __shared__ double sP[CHUNK_PTS * 3];
+    __shared__ double sRed[4];
+    const int ck = blockIdx.x, tid = threadIdx.x;
+    const int ob = A.ck_obs[ck], nobs = A.ck_obs[ck + 1] - ob;
+    const int pb = A.ck_pt[ck], npts = A.ck_pt[ck + 1] - pb;
+    for (int i = tid; i < npts * 3; i += CHUNK_OBS) sP[i] = 0.0;
+    __syncthreads();
+    const bool act = tid < nobs;
+    int lp = 0, cam = 0;
+    double r0 = 0, r1 = 0, w0 = 0, w1 = 0, a0 = 0, a1 = 0, Jp[2][3], X0 = 0, X1 = 0, X2 = 0, uo = 0, vo = 0;
+    if (act) {
+        const int o = ob + tid;
+        cam = A.o_cam[o];
+        const int p = A.o_pt[o];
+        lp = p - pb;
+        CamAux ca;
+        load_aux(A.aux, cam, ca);
+        X0 = A.points[3 * (size_t)p]; X1 = A.points[3 * (size_t)p + 1]; X2 = A.points[3 * (size_t)p + 2];
+        const double2 xy = reinterpret_cast<const double2 *>(A.o_xy)[o];
+        uo = xy.x; vo = xy.y;
+        ObsLin L;
+        linearize(ca, X0, X1, X2, uo, vo, A.loss, A.inv_fs2, L);
+        r0 = L.r[0]; r1 = L.r[1]; w0 = L.w[0]; w1 = L.w[1];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { Jp[0][j] = L.Jp[0][j]; Jp[1][j] = L.Jp[1][j]; }
+        const int f = A.cam_free[cam];
+        if (f >= 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const double d = A.dx[(size_t)f * 6 + i];
+                a0 += L.Jc[0][i] * d; a1 += L.Jc[1][i] * d;
+            }
+        }
+        const double wa0 = w0 * a0, wa1 = w1 * a1;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) atomicAdd(&sP[lp * 3 + j], Jp[0][j] * wa0 + Jp[1][j] * wa1);
+    }
+    __syncthreads();
+    double dp2 = 0.0, xp2 = 0.0;
+    if (tid < npts) {
+        const size_t p = (size_t)(pb + tid);
+        const double *li = &A.pt_linv[p * 6], *uu = &A.pt_u[p * 3];
+        const double i00 = li[0], i10 = li[1], i11 = li[2], i20 = li[3], i21 = li[4], i22 = li[5];
+        const double s0 = sP[tid * 3], s1 = sP[tid * 3 + 1], s2 = sP[tid * 3 + 2];
+        const double y0 = uu[0] + i00 * s0;
+        const double y1 = uu[1] + i10 * s0 + i11 * s1;
+        const double y2 = uu[2] + i20 * s0 + i21 * s1 + i22 * s2;
+        const double d0 = -(i00 * y0 + i10 * y1 + i20 * y2);
+        const double d1 = -(i11 * y1 + i21 * y2);
+        const double d2 = -(i22 * y2);
+        sP[tid * 3] = d0; sP[tid * 3 + 1] = d1; sP[tid * 3 + 2] = d2;
+        const double p0 = A.points[3 * p], p1 = A.points[3 * p + 1], p2 = A.points[3 * p + 2];
+        A.points_t[3 * p] = p0 + d0; A.points_t[3 * p + 1] = p1 + d1; A.points_t[3 * p + 2] = p2 + d2;
+        dp2 = d0 * d0 + d1 * d1 + d2 * d2;
+        xp2 = p0 * p0 + p1 * p1 + p2 * p2;
+    }
+    __syncthreads();
+    double pred = 0.0, ft = 0.0;
+    if (act) {
+        const double d0 = sP[lp * 3], d1 = sP[lp * 3 + 1], d2 = sP[lp * 3 + 2];
+        const double jd0 = a0 + Jp[0][0] * d0 + Jp[0][1] * d1 + Jp[0][2] * d2;
+        const double jd1 = a1 + Jp[1][0] * d0 + Jp[1][1] * d1 + Jp[1][2] * d2;
+        pred = -(w0 * jd0 * (r0 + 0.5 * jd0) + w1 * jd1 * (r1 + 0.5 * jd1));
+        double u, v;
+        project_only(A.aux_t, cam, X0 + d0, X1 + d1, X2 + d2, u, v);
+        const double e0 = u - uo, e1 = v - vo;
+        double rho0, rho1, wd;
+        loss_eval(A.loss, e0 * e0 * A.inv_fs2, rho0, wd);
+        loss_eval(A.loss, e1 * e1 * A.inv_fs2, rho1, wd);
+        ft = A.half_fs2 * (rho0 + rho1);
+    }
+    pred = block_sum256(pred, sRed);
+    ft = block_sum256(ft, sRed);
+    dp2 = block_sum256(dp2, sRed);
+    xp2 = block_sum256(xp2, sRed);
+    if (tid == 0) {
+        double *o = &A.ck_part[(size_t)ck * 4];
+        o[0] = pred; o[1] = ft; o[2] = dp2; o[3] = xp2;
+    }
+}
+
+// ------------------------------------------------------------------ deterministic reductions + LM control
+// out[k] = sum over i of in[i*stride + k] (k < stride), fixed order -> bitwise reproducible.
+__global__ void k_reduce_sum(int n, int stride, const double *__restrict__ in, double *__restrict__ out) {
+    __shared__ double red[4];
+    for (int k = 0; k < stride; ++k) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < n; i += 256) s += in[(size_t)i * stride + k];
+        s = block_sum256(s, red);
+        if (threadIdx.x == 0) out[k] = s;
+        __syncthreads();
+    }
+}
+__global__ void k_reduce_max(int n, const double *__restrict__ in, double *__restrict__ out) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s = fmax(s, in[i]);
+    s = block_max256(s, red);
+    if (threadIdx.x == 0) out[0] = s;
+}
+
+__global__ void k_add_scalar(double *p, double v) { *p += v; }
+
+// after a build: F and ||g||_inf into the state. sums[0] = F (already all-reduced), gm[0], gm[1] = point / camera maxima
+__global__ void k_state_after_build(LmState *st, const double *sums, const double *gm) {
+    st->F = sums[0];
+    st->gmax = fmax(gm[0], gm[1]);
+}
+
+// after a trial step: gain ratio, accept / reject, damping update, termination (scipy _lsq/common.py:705-717)
+// step[0..3] = pred, F_trial, |dp|^2, |x_p|^2 (all-reduced); cams[0..1] = |dc|^2, |x_c|^2 (replicated)
+__global__ void k_decide(LmState *st, const double *step, const double *cams, double x2_const, double ftol, double xtol) {
+    const double pred = step[0], Ft = step[1];
+    const double F = st->F;
+    const double dF = F - Ft;
+    const double step_norm = sqrt(step[2] + cams[0]);
+    const double x_norm = sqrt(step[3] + cams[1] + x2_const);
+    double rho = (pred > 0.0) ? dF / pred : -1.0;
+    const bool finite = (Ft == Ft) && (fabs(Ft) < 1e300) && (pred == pred);
+    if (!finite) rho = -1.0;
+    st->F_trial = Ft; st->pred = pred; st->rho = rho; st->dF = dF;
+    st->step_norm = step_norm; st->x_norm = x_norm;
+    st->iter += 1;
+    const bool ftol_ok = finite && dF < ftol * F && rho > 0.25;
+    const bool xtol_ok = finite && step_norm < xtol * (xtol + x_norm);
+    const bool accept = finite && rho > 0.0;
+    st->accept = accept ? 1 : 0;
+    if (accept) {
+        st->n_accept += 1;
+        const double t = 2.0 * rho - 1.0;
+        st->lambda *= fmax(1.0 / 3.0, 1.0 - t * t * t);
+        st->nu = 2.0;
+        st->F = Ft;
+    } else {
+        st->lambda *= st->nu;
+        st->nu *= 2.0;
+    }
+    st->lambda = fmin(fmax(st->lambda, 1e-12), 1e12);
+    int term = 0;
+    if (ftol_ok && xtol_ok) term = 4;
+    else if (ftol_ok) term = 2;
+    else if (xtol_ok) term = 3;
+    st->terminate = term;
+}
+
+// ------------------------------------------------------------------ evaluation kernels, caller's order
+__global__ void k_eval_residuals(long long n_obs, const double *__restrict__ aux, const double *__restrict__ points,
+                                 const int *__restrict__ obs_cam, const int *__restrict__ obs_pt,
+                                 const double *__restrict__ obs_xy, double *__restrict__ out) {
+    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n_obs) return;
+    const int p = obs_pt[o];
+    double u, v;
+    project_only(aux, obs_cam[o], points[3 * (size_t)p], points[3 * (size_t)p + 1], points[3 * (size_t)p + 2], u, v);
+    out[2 * o] = u - obs_xy[2 * o];
+    out[2 * o + 1] = v - obs_xy[2 * o + 1];
+}
+
+__global__ void k_eval_cost(long long n_obs, const double *__restrict__ aux, const double *__restrict__ points,
+                            const int *__restrict__ obs_cam, const int *__restrict__ obs_pt,
+                            const double *__restrict__ obs_xy, int loss, double inv_fs2, double half_fs2,
+                            double *__restrict__ blk_cost, double *__restrict__ blk_rsum) {
+    __shared__ double red[4];
+    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    double c = 0.0, rs = 0.0;
+    if (o < n_obs) {
+        const int p = obs_pt[o];
+        double u, v;
+        project_only(aux, obs_cam[o], points[3 * (size_t)p], points[3 * (size_t)p + 1], points[3 * (size_t)p + 2], u, v);
+        const double e0 = u - obs_xy[2 * o], e1 = v - obs_xy[2 * o + 1];
+        double rho0, rho1, wd;
+        loss_eval(loss, e0 * e0 * inv_fs2, rho0, wd);
+        loss_eval(loss, e1 * e1 * inv_fs2, rho1, wd);
+        c = half_fs2 * (rho0 + rho1);
+        rs = e0 + e1;
+    }
+    c = block_sum256(c, red);
+    rs = block_sum256(rs, red);
+    if (threadIdx.x == 0) { blk_cost[blockIdx.x] = c; blk_rsum[blockIdx.x] = rs; }
+}
+
+__global__ void k_eval_jacobian(long long n_obs, const double *__restrict__ aux, const double *__restrict__ points,
+                                const int *__restrict__ obs_cam, const int *__restrict__ obs_pt,
+                                double *__restrict__ jc, double *__restrict__ jp) {
+    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n_obs) return;
+    const int p = obs_pt[o];
+    CamAux ca;
+    load_aux(aux, obs_cam[o], ca);
+    ObsLin L;
+    linearize(ca, points[3 * (size_t)p], points[3 * (size_t)p + 1], points[3 * (size_t)p + 2], 0.0, 0.0, 0, 1.0, L);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) jc[12 * o + 6 * k + i] = L.Jc[k][i];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) jp[6 * o + 3 * k + j] = L.Jp[k][j];
+    }
+}
+
+// per-camera mean L2 reprojection error with the full K (utils.py:271-276): sums by atomics
+__global__ void k_eval_reproj(long long n_obs, const double *__restrict__ aux, const double *__restrict__ cam_k,
+                              const double *__restrict__ points, const int *__restrict__ obs_cam,
+                              const int *__restrict__ obs_pt, const double *__restrict__ obs_xy,
+                              double *__restrict__ cam_sum, double *__restrict__ cam_cnt) {
+    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n_obs) return;
+    const int p = obs_pt[o], c = obs_cam[o];
+    const double *a = aux + (size_t)c * BA_CAM_AUX;
+    const double X0 = points[3 * (size_t)p], X1 = points[3 * (size_t)p + 1], X2 = points[3 * (size_t)p + 2];
+    const double x = a[0] * X0 + a[1] * X1 + a[2] * X2 + a[18];
+    const double y = a[3] * X0 + a[4] * X1 + a[5] * X2 + a[19];
+    const double z = a[6] * X0 + a[7] * X1 + a[8] * X2 + a[20];
+    const double *K = cam_k + 9 * (size_t)c;
+    const double h0 = K[0] * x + K[1] * y + K[2] * z;
+    const double h1 = K[3] * x + K[4] * y + K[5] * z;
+    const double h2 = K[6] * x + K[7] * y + K[8] * z;
+    const double e0 = obs_xy[2 * o] - h0 / h2, e1 = obs_xy[2 * o + 1] - h1 / h2;
+    atomicAdd(&cam_sum[c], sqrt(e0 * e0 + e1 * e1));
+    atomicAdd(&cam_cnt[c], 1.0);
+}
+
+}  // namespace ba

@@ -1,0 +1,229 @@
+// Host-side symbolic analysis (see ba_symbolic.h).  Plain C++: also compiled by g++ for the
+// CPU-only structure tests (ba_analyze needs no GPU).
+#include "ba_symbolic.h"
+
+#include <algorithm>
+#include <numeric>
+#include <unordered_map>
+
+#include "../../include/ba_hip.h"
+
+namespace ba {
+
+int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *cam_fixed,
+                      const int32_t *obs_cam, const int32_t *obs_pt, Symbolic &s, const char **err) {
+    s = Symbolic();
+    s.n_cams = n_cams;
+    s.n_points = n_points;
+    s.n_obs = n_obs;
+    s.cam_free.assign(n_cams, -1);
+    for (int c = 0; c < n_cams; ++c)
+        if (!cam_fixed[c]) {
+            s.cam_free[c] = s.n_free++;
+            s.free_cam.push_back(c);
+        }
+    // --- observations per point, validity -------------------------------------------------
+    std::vector<int32_t> cnt(n_points + 1, 0);
+    for (int64_t k = 0; k < n_obs; ++k) {
+        if (obs_cam[k] < 0 || obs_cam[k] >= n_cams || obs_pt[k] < 0 || obs_pt[k] >= n_points) {
+            *err = "observation index out of range";
+            return BA_ERR_INVALID;
+        }
+        cnt[obs_pt[k]]++;
+    }
+    // --- point order: observed points sorted by (min camera, max camera), unobserved last ----
+    std::vector<int32_t> cmin(n_points, INT32_MAX), cmax(n_points, -1);
+    for (int64_t k = 0; k < n_obs; ++k) {
+        int p = obs_pt[k], c = obs_cam[k];
+        cmin[p] = std::min(cmin[p], c);
+        cmax[p] = std::max(cmax[p], c);
+    }
+    s.pt_order.resize(n_points);
+    std::iota(s.pt_order.begin(), s.pt_order.end(), 0);
+    std::stable_sort(s.pt_order.begin(), s.pt_order.end(), [&](int a, int b) {
+        bool ea = cnt[a] == 0, eb = cnt[b] == 0;
+        if (ea != eb) return eb;  // observed first
+        if (ea) return false;
+        if (cmin[a] != cmin[b]) return cmin[a] < cmin[b];
+        return cmax[a] < cmax[b];
+    });
+    std::vector<int32_t> pt_inv(n_points);
+    s.n_pts_obs = 0;
+    for (int i = 0; i < n_points; ++i) {
+        pt_inv[s.pt_order[i]] = i;
+        if (cnt[s.pt_order[i]] > 0) s.n_pts_obs = i + 1;
+    }
+    // --- observations sorted by (internal point, camera) --------------------------------
+    std::vector<int64_t> pstart(n_points + 1, 0);
+    for (int i = 0; i < n_points; ++i) pstart[i + 1] = pstart[i] + cnt[s.pt_order[i]];
+    s.obs_order.resize(n_obs);
+    {
+        std::vector<int64_t> fill(pstart.begin(), pstart.end() - 1);
+        for (int64_t k = 0; k < n_obs; ++k) s.obs_order[fill[pt_inv[obs_pt[k]]]++] = k;
+        for (int i = 0; i < s.n_pts_obs; ++i)
+            std::sort(s.obs_order.begin() + pstart[i], s.obs_order.begin() + pstart[i + 1],
+                      [&](int64_t a, int64_t b) { return obs_cam[a] != obs_cam[b] ? obs_cam[a] < obs_cam[b] : a < b; });
+    }
+    s.o_cam.resize(n_obs);
+    s.o_pt.resize(n_obs);
+    s.o_lcam.resize(n_obs);
+    for (int64_t k = 0; k < n_obs; ++k) {
+        s.o_cam[k] = obs_cam[s.obs_order[k]];
+        s.o_pt[k] = pt_inv[obs_pt[s.obs_order[k]]];
+    }
+    double track_sum = 0;
+    for (int i = 0; i < s.n_pts_obs; ++i) {
+        int L = (int)(pstart[i + 1] - pstart[i]);
+        s.max_track = std::max(s.max_track, L);
+        track_sum += L;
+    }
+    if (s.max_track > CHUNK_OBS) {
+        *err = "a point has more than BA_MAX_TRACK observations";
+        return BA_ERR_UNSUPPORTED;
+    }
+    // --- greedy chunking -----------------------------------------------------------------
+    std::vector<int32_t> cam_stamp(std::max(s.n_free, 1), -1), cam_slot(std::max(s.n_free, 1), 0);
+    std::unordered_map<int64_t, int32_t> pair_map;
+    std::vector<int64_t> ck_pair_key;  // parallel to ck_pair_slot
+    s.ck_obs.push_back(0);
+    s.ck_pt.push_back(0);
+    s.ck_cam.push_back(0);
+    s.ck_pair.push_back(0);
+    s.ck_pe.push_back(0);
+    int chunk = 0, cur_obs = 0, cur_pts = 0, cur_cams = 0;
+    int64_t obs_base = 0;
+    auto close_chunk = [&](int next_pt, int64_t next_obs) {
+        s.ck_obs.push_back((int32_t)next_obs);
+        s.ck_pt.push_back(next_pt);
+        s.ck_cam.push_back((int32_t)s.ck_cam_list.size());
+        s.ck_pair.push_back((int32_t)ck_pair_key.size());
+        s.ck_pe.push_back((int64_t)s.pair_entries.size());
+        s.max_chunk_cams = std::max(s.max_chunk_cams, cur_cams);
+        s.max_chunk_pairs = std::max(s.max_chunk_pairs, (int)pair_map.size());
+        pair_map.clear();
+        ++chunk;
+        cur_obs = cur_pts = cur_cams = 0;
+        obs_base = next_obs;
+    };
+    std::vector<int32_t> fidx;
+    for (int i = 0; i < s.n_pts_obs; ++i) {
+        const int64_t b = pstart[i], e = pstart[i + 1];
+        const int L = (int)(e - b);
+        fidx.resize(L);
+        for (int a = 0; a < L; ++a) fidx[a] = s.cam_free[s.o_cam[b + a]];
+        bool cut = cur_obs + L > CHUNK_OBS || cur_pts + 1 > CHUNK_PTS;
+        if (!cut && cur_obs >= CHUNK_OBS / 4) {
+            // soft cut: would this point overflow the LDS tiles?
+            int newc = 0, newp = 0;
+            for (int a = 0; a < L; ++a) {
+                if (fidx[a] < 0) continue;
+                bool seen = cam_stamp[fidx[a]] == chunk;
+                for (int a2 = 0; a2 < a && !seen; ++a2) seen = fidx[a2] == fidx[a];
+                if (!seen) ++newc;
+                for (int c = a; c < L; ++c) {
+                    if (fidx[c] < 0) continue;
+                    int64_t key = ((int64_t)fidx[a] << 32) | (uint32_t)fidx[c];
+                    if (!pair_map.count(key)) ++newp;  // (duplicates inside the point over-count: harmless)
+                }
+            }
+            if (cur_cams + newc > CHUNK_CAMS || (int)pair_map.size() + newp > CHUNK_PAIRS) cut = true;
+        }
+        if (cut && cur_pts > 0) close_chunk(i, b);
+        for (int a = 0; a < L; ++a) {
+            int f = fidx[a];
+            int16_t slot = -2;
+            if (f >= 0) {
+                if (cam_stamp[f] != chunk) {
+                    cam_stamp[f] = chunk;
+                    if (cur_cams < CHUNK_CAMS) {
+                        cam_slot[f] = cur_cams++;
+                        s.ck_cam_list.push_back(f);
+                    } else {
+                        cam_slot[f] = -1;
+                    }
+                }
+                slot = (int16_t)cam_slot[f];
+                if (slot < 0) {
+                    slot = -1;
+                    s.n_direct_cam_obs++;
+                }
+            }
+            s.o_lcam[b + a] = slot;
+        }
+        for (int a = 0; a < L; ++a) {
+            if (fidx[a] < 0) continue;
+            for (int c = a; c < L; ++c) {
+                if (fidx[c] < 0) continue;
+                int64_t key = ((int64_t)fidx[a] << 32) | (uint32_t)fidx[c];
+                auto it = pair_map.find(key);
+                int32_t lp;
+                if (it == pair_map.end()) {
+                    lp = (int32_t)pair_map.size();
+                    pair_map.emplace(key, lp);
+                    ck_pair_key.push_back(key);
+                } else {
+                    lp = it->second;
+                }
+                const uint32_t oi = (uint32_t)(b + a - obs_base), oj = (uint32_t)(b + c - obs_base);
+                s.pair_entries.push_back(oi | (oj << 8) | ((uint32_t)lp << 16));
+                if (lp >= CHUNK_PAIRS) s.n_direct_pairs++;
+                if (c != a && fidx[c] == fidx[a]) {  // same camera observing the point twice
+                    s.pair_entries.push_back(oj | (oi << 8) | ((uint32_t)lp << 16));
+                    if (lp >= CHUNK_PAIRS) s.n_direct_pairs++;
+                }
+            }
+        }
+        cur_obs += L;
+        cur_pts += 1;
+    }
+    if (cur_pts > 0) close_chunk(s.n_pts_obs, pstart[s.n_pts_obs]);
+    // slots are resolved by finalize_pattern (the pattern may be a union over ranks)
+    s.ck_pair_slot.assign(ck_pair_key.size(), -1);
+    s.raw_keys.swap(ck_pair_key);
+    s.mean_track = s.n_pts_obs ? track_sum / s.n_pts_obs : 0.0;
+    return BA_OK;
+}
+
+void finalize_pattern(Symbolic &s, const std::vector<int64_t> &extra_keys) {
+    const std::vector<int64_t> &raw = s.raw_keys;  // per-chunk keys, same order as ck_pair_slot
+    std::vector<int64_t> keys(raw);
+    keys.insert(keys.end(), extra_keys.begin(), extra_keys.end());
+    for (int f = 0; f < s.n_free; ++f) keys.push_back(((int64_t)f << 32) | (uint32_t)f);  // every diagonal block
+    std::sort(keys.begin(), keys.end());
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    s.upper_keys = keys;
+    for (size_t k = 0; k < raw.size(); ++k)
+        s.ck_pair_slot[k] = (int32_t)(std::lower_bound(keys.begin(), keys.end(), raw[k]) - keys.begin());
+    // full CSR view
+    const int nf = s.n_free;
+    s.diag_slot.assign(nf, -1);
+    std::vector<int32_t> rowcnt(nf + 1, 0);
+    for (size_t k = 0; k < keys.size(); ++k) {
+        int i = (int)(keys[k] >> 32), j = (int)(keys[k] & 0xffffffff);
+        rowcnt[i]++;
+        if (i != j) rowcnt[j]++;
+        else s.diag_slot[i] = (int32_t)k;
+    }
+    s.bsr_row.assign(nf + 1, 0);
+    for (int i = 0; i < nf; ++i) s.bsr_row[i + 1] = s.bsr_row[i] + rowcnt[i];
+    s.bsr_col.assign(s.bsr_row[nf], 0);
+    s.bsr_src.assign(s.bsr_row[nf], 0);
+    std::vector<int32_t> fill(s.bsr_row.begin(), s.bsr_row.end() - 1);
+    // lower entries of row j come from keys (i<j, j) which sort by i: emit them first, then upper
+    for (size_t k = 0; k < keys.size(); ++k) {
+        int i = (int)(keys[k] >> 32), j = (int)(keys[k] & 0xffffffff);
+        if (i != j) {
+            int pos = fill[j]++;
+            s.bsr_col[pos] = i;
+            s.bsr_src[pos] = (int32_t)((uint32_t)k | 0x80000000u);
+        }
+    }
+    for (size_t k = 0; k < keys.size(); ++k) {
+        int i = (int)(keys[k] >> 32), j = (int)(keys[k] & 0xffffffff);
+        int pos = fill[i]++;
+        s.bsr_col[pos] = j;
+        s.bsr_src[pos] = (int32_t)k;
+    }
+}
+
+}  // namespace ba

@@ -1,0 +1,61 @@
+// Host-side symbolic analysis of a bundle-adjustment problem (plain C++, no HIP).
+//
+// The reference builds one boolean Jacobian sparsity matrix per solve with a Python loop
+// (BundleAdjustment.py:154-198).  The engine needs a different structure, built once per
+// problem and reused by every LM iteration:
+//   * points re-ordered so that neighbouring points see the same cameras, observations sorted
+//     by (point, camera);
+//   * "chunks": runs of consecutive points (<= CHUNK_OBS observations) that one workgroup
+//     linearises and eliminates, with the chunk's cameras and camera pairs numbered locally so
+//     the per-camera blocks and Schur-complement blocks can be accumulated in LDS;
+//   * the block-sparse pattern of the reduced camera system (upper triangle + full CSR view).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace ba {
+
+constexpr int CHUNK_OBS = 256;   // observations per chunk = threads per workgroup
+constexpr int CHUNK_PTS = 128;   // points per chunk (LDS slots)
+constexpr int CHUNK_CAMS = 32;   // cameras with an LDS tile per chunk
+constexpr int CHUNK_PAIRS = 80;  // camera pairs with an LDS tile per chunk
+
+struct Symbolic {
+    int n_cams = 0, n_free = 0, n_points = 0, n_pts_obs = 0;
+    int64_t n_obs = 0;
+    int max_track = 0;
+    double mean_track = 0;
+    std::vector<int32_t> cam_free;   // [n_cams] free-camera index or -1
+    std::vector<int32_t> free_cam;   // [n_free] camera index
+    std::vector<int32_t> pt_order;   // internal point -> caller's point index (observed first)
+    std::vector<int64_t> obs_order;  // internal observation -> caller's observation index
+    std::vector<int32_t> o_cam;      // [n_obs] camera index, internal order
+    std::vector<int32_t> o_pt;       // [n_obs] internal point index
+    std::vector<int16_t> o_lcam;     // [n_obs] chunk-local camera slot, -1 = no LDS tile (fixed cameras: -2)
+    // chunks
+    std::vector<int32_t> ck_obs;     // [n_chunks+1]
+    std::vector<int32_t> ck_pt;      // [n_chunks+1] (internal point range)
+    std::vector<int32_t> ck_cam;     // [n_chunks+1] into ck_cam_list
+    std::vector<int32_t> ck_cam_list;   // free-camera index per local slot
+    std::vector<int32_t> ck_pair;    // [n_chunks+1] into ck_pair_slot
+    std::vector<int32_t> ck_pair_slot;  // upper-triangle block slot per local pair
+    std::vector<int64_t> raw_keys;      // (i<<32 | j) per local pair, same order as ck_pair_slot
+    std::vector<int64_t> ck_pe;      // [n_chunks+1] into pair_entries
+    std::vector<uint32_t> pair_entries; // oi | oj<<8 | local_pair<<16 (oi, oj: observation index inside the chunk)
+    // reduced camera system pattern
+    std::vector<int64_t> upper_keys; // sorted unique (i<<32 | j), i <= j, free-camera indices
+    std::vector<int32_t> diag_slot;  // [n_free]
+    std::vector<int32_t> bsr_row;    // [n_free+1] full (both triangles) pattern
+    std::vector<int32_t> bsr_col;    // [nnz_full]
+    std::vector<int32_t> bsr_src;    // [nnz_full] upper slot; bit 31 set = use the transposed block
+    int64_t n_direct_pairs = 0, n_direct_cam_obs = 0;
+    int max_chunk_cams = 0, max_chunk_pairs = 0;
+};
+
+// Phase A: ordering + chunking + this problem's own pair keys.  Returns 0 or a BA_ERR_* code.
+int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *cam_fixed,
+                      const int32_t *obs_cam, const int32_t *obs_pt, Symbolic &s, const char **err);
+// Phase B: final pattern = own keys U extra keys; resolves chunk-local pairs to block slots.
+void finalize_pattern(Symbolic &s, const std::vector<int64_t> &extra_keys);
+
+}  // namespace ba

@@ -1,0 +1,12 @@
+#!/bin/bash
+# Builds libba_hip.so (gfx950) in-tree.  hipcc cross-compiles without a GPU.
+set -e
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+OUT=../libba_hip.so
+mkdir -p build
+$HIPCC -O3 -std=c++17 --offload-arch=gfx950 -munsafe-fp-atomics -fPIC -Wall -Wno-unused-function ${BA_EXTRA_FLAGS} \
+    -c ba_engine.hip -o build/ba_engine.o
+g++ -O2 -std=c++17 -fPIC -Wall -c ba_symbolic.cpp -o build/ba_symbolic.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC build/ba_engine.o build/ba_symbolic.o -o $OUT
+echo "built $(realpath $OUT)"

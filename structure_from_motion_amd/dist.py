@@ -1,0 +1,85 @@
+"""Point-sharded multi-GPU bundle adjustment (one process per GPU, RCCL over xGMI).
+
+Every residual couples one camera and one point (``BundleAdjustment.py:185-196``), so a rank
+that owns a disjoint set of points together with ALL their observations (cameras replicated)
+builds its partial reduced camera system without communication.  Per LM step the ranks then
+exchange:
+
+  1. one all-reduce (sum) of the contiguous buffer [S blocks | U | g_c | g_red | cost],
+     one all-reduce (max) of the point-gradient norm;
+  2. the replicated PCG solve (no communication), then a broadcast of rank 0's camera step so
+     that every rank holds bit-identical cameras;
+  3. one 4-double all-reduce of the step statistics (model reduction, trial cost, norms) so that
+     every rank takes the same accept / reject decision.
+
+The collectives are ``torch.distributed`` calls (backend "nccl" = RCCL on ROCm) on tensors that
+alias the library's device buffers; the library calls back into :func:`make_collective`.
+"""
+import numpy as np
+
+from . import _capi
+
+
+class _DevArray:
+    """Minimal ``__cuda_array_interface__`` holder so torch can alias a raw device pointer."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def make_collective(group=None):
+    """Collective callback for ``Handle.set_collective`` backed by torch.distributed."""
+    import torch
+    import torch.distributed as dist
+
+    def coll(ptr, count, op):
+        t = torch.as_tensor(_DevArray(ptr, count), device="cuda")
+        if op == _capi.REDUCE_SUM:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        elif op == _capi.REDUCE_MAX:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        else:
+            dist.broadcast(t, src=0, group=group)
+        torch.cuda.current_stream().synchronize()
+        return 0
+    return coll
+
+
+def union_pattern(local_pairs, all_gather_object):
+    """Union of the ranks' co-visibility pairs: every rank must use ONE block pattern so the
+    reduced-system buffers line up element by element for the all-reduce."""
+    gathered = all_gather_object(np.ascontiguousarray(local_pairs, dtype=np.int32))
+    allp = np.concatenate([np.asarray(g, dtype=np.int32).reshape(-1, 2) for g in gathered], axis=0)
+    return np.unique(allp, axis=0)
+
+
+def shard_points(prob, rank, world):
+    """Contiguous point shards balanced by observation count; a rank gets its points (re-indexed)
+    and all their observations, cameras are replicated.  Returns (shard, point_index)."""
+    n_p = len(prob["points"])
+    cnt = np.bincount(prob["obs_pt"], minlength=n_p)
+    csum = np.concatenate([[0], np.cumsum(cnt)])
+    total = csum[-1]
+    bounds = [int(np.searchsorted(csum, total * r / world, side="left")) for r in range(world)] + [n_p]
+    bounds[0] = 0
+    lo, hi = bounds[rank], bounds[rank + 1]
+    m = (prob["obs_pt"] >= lo) & (prob["obs_pt"] < hi)
+    shard = dict(cam_pose=prob["cam_pose"], cam_intr=prob["cam_intr"], cam_fixed=prob["cam_fixed"],
+                 points=prob["points"][lo:hi], obs_cam=prob["obs_cam"][m],
+                 obs_pt=(prob["obs_pt"][m] - lo).astype(np.int32), obs_xy=prob["obs_xy"][m])
+    return shard, np.arange(lo, hi)
+
+
+def create_sharded_handle(shard, rank, world, group=None, **opts):
+    """Handle for this rank's shard with the shared pattern and the RCCL collectives installed."""
+    import torch.distributed as dist
+    h = _capi.Handle(_capi.Arrays.from_dict(shard), **opts)
+    if world > 1:
+        def gather(obj):
+            out = [None] * world
+            dist.all_gather_object(out, obj, group=group)
+            return out
+        h.set_pattern(union_pattern(h.pattern(), gather))
+        h.set_collective(make_collective(group), rank, world)
+    return h

@@ -111,8 +111,9 @@ def run_case(ref, name, prob, f_scale, max_nfev, visited_perm=None, tight=True, 
     if not big:
         J2 = approx_derivative(fun, x0, method="2-point", f0=f0, sparsity=(sparsity, groups)).tocoo()
         data.update(j2_row=J2.row.astype(np.int32), j2_col=J2.col.astype(np.int32), j2_val=J2.data)
-        Ja = approx_derivative(fun, x0, method="3-point", rel_step=1e-3, sparsity=(sparsity, groups)).toarray()
-        Jb = approx_derivative(fun, x0, method="3-point", rel_step=5e-4, sparsity=(sparsity, groups)).toarray()
+        hstep = 1e-3 * np.maximum(1.0, np.abs(x0))  # absolute steps (rel_step would scale with |x0| ~ 0)
+        Ja = approx_derivative(fun, x0, method="3-point", abs_step=hstep, sparsity=(sparsity, groups)).toarray()
+        Jb = approx_derivative(fun, x0, method="3-point", abs_step=0.5 * hstep, sparsity=(sparsity, groups)).toarray()
         Jh = ((4.0 * Jb - Ja) / 3.0) * sparsity.toarray()
         from scipy.sparse import coo_matrix
         Jh = coo_matrix(Jh)

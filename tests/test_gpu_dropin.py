@@ -1,0 +1,91 @@
+"""GPU: the drop-in Python interface (same calls as the reference's Reconstruction.py makes)."""
+import copy
+
+import numpy as np
+import pytest
+from conftest import load_golden
+from test_host_logic import _image_data_from_golden
+
+from oracle import ba_oracle as O
+from structure_from_motion_amd import BundleAdjustment as BA
+from structure_from_motion_amd.geometry import matrix_to_rvec
+
+pytestmark = pytest.mark.gpu
+
+
+def _errors(image_data, pts, ids):
+    out = {}
+    P = np.array([p[:3] for p in pts], dtype=np.float64)
+    for cid in ids:
+        R, t, K, ref, _, kp = image_data[cid]
+        idx = [(k, r) for k, r in enumerate(ref) if r != -1]
+        X = P[[r for _, r in idx]]
+        xy = np.array([kp[k].pt for k, _ in idx])
+        pc = R @ X.T + t.reshape(3, 1)
+        ph = K.astype(np.float64) @ pc
+        out[cid] = float(np.mean(np.linalg.norm(xy - (ph[:2] / ph[2]).T, axis=1)))
+    return out
+
+
+def test_final_and_inter_ba_against_reference_results(gpu):
+    g = load_golden("marshalling")
+    ids, image_data, pts = _image_data_from_golden(g)
+    assert bool(g["final_ok"]) and bool(g["inter_ok"])
+    for fn, key in ((lambda d: BA.final_ba(d, pts, ids, verbose=False), "final"),
+                    (lambda d: BA.inter_ba(d, pts, ids, ba_interval=2, verbose=True), "inter")):
+        d = copy.deepcopy(image_data)
+        out_pts, out_d, ok = fn(d)
+        assert ok is True and out_d is d
+        assert len(out_pts) == len(pts) and all(len(p) == 6 for p in out_pts)
+        assert [p[3:] for p in out_pts] == [p[3:] for p in pts]            # colours preserved
+        assert out_pts is not pts and pts[0][0] == float(g["points"][0, 0])  # inputs not mutated
+        for i, cid in enumerate(ids):
+            assert out_d[cid][0].shape == (3, 3) and out_d[cid][1].shape == (3, 1)
+            assert out_d[cid][0].dtype == np.float64 and out_d[cid][1].dtype == np.float64
+        # anchored cameras (first two visited, < 15 images) unchanged
+        for cid in ids[:2]:
+            np.testing.assert_array_equal(out_d[cid][0], image_data[cid][0])
+        # per-camera mean reprojection error within 1e-3 px of the reference's converged result
+        ref_d = copy.deepcopy(image_data)
+        for i, cid in enumerate(ids):
+            e = list(ref_d[cid]); e[0] = g[f"{key}_R"][i]; e[1] = g[f"{key}_t"][i].reshape(3, 1); ref_d[cid] = tuple(e)
+        ref_pts = [[*g[f"{key}_pts"][i], 0.1, 0.2, 0.3] for i in range(len(pts))]
+        e_ref = _errors(ref_d, ref_pts, ids)
+        e_our = BA.compute_ba_reprojection_errors(out_d, out_pts, ids)
+        e_chk = _errors(out_d, out_pts, ids)
+        for cid in ids:
+            assert abs(e_our[cid] - e_chk[cid]) < 1e-9          # HIP reprojection-error kernel vs NumPy formula
+            assert abs(e_our[cid] - e_ref[cid]) < 1e-3
+    r = BA.inter_ba(copy.deepcopy(image_data), pts, ids[:5], ba_interval=2, verbose=False)
+    assert r[2] is False and bool(g["inter_skip_ok"]) is False
+
+
+def test_global_ba_containers_and_gauge(gpu):
+    g = load_golden("ring16_dense")
+    nc = len(g["cam_pose"])
+    ids = [int(v) for v in g["cam_ids"]]
+    R = O.rodrigues(g["cam_pose"][:, :3])
+    cams = {}
+    for i, cid in enumerate(ids):
+        fx, fy, cx, cy = g["cam_intr"][i]
+        cams[cid] = {"R": R[i].copy(), "t": g["cam_pose"][i, 3:].reshape(3, 1).copy(),
+                     "K": np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])}
+    pts = [[*map(float, p), *map(float, c)] for p, c in zip(g["points"], g["colors"])]
+    obs = [{"camera_id": ids[int(c)], "point_idx": int(p), "pixel": xy.copy()}
+           for c, p, xy in zip(g["obs_cam"], g["obs_pt"], g["obs_xy"])]
+    visited = [int(v) for v in g["visited_ids"]]
+    new_c, new_p, ok = BA.global_bundle_adjustment(cams, pts, obs, visited, robust_loss="huber",
+                                                   loss_f_scale=1.0, max_nfev=300, verbose=1)
+    assert ok is True and list(new_c.keys()) == ids and nc >= 15
+    assert new_c[visited[0]]["R"] is cams[visited[0]]["R"]          # anchored: shallow copy shares arrays
+    assert new_c[visited[1]]["R"] is not cams[visited[1]]["R"]      # >= 15 images: second camera is free
+    assert tuple(g["ref_out_t_shape"]) == new_c[ids[-1]]["t"].shape == (3, 1)
+    assert len(new_p[0]) == int(g["ref_out_point_len"]) == 6
+    # cost of the returned containers through the oracle objective: within 1e-6 of the reference's converged cost
+    cp = np.array([np.concatenate([matrix_to_rvec(new_c[c]["R"]), new_c[c]["t"].reshape(3)]) for c in ids])
+    P = np.array([p[:3] for p in new_p], dtype=np.float64)
+    f = O.residuals(cp, g["cam_intr"], P, g["obs_cam"], g["obs_pt"], g["obs_xy"])
+    c = O.cost(f, 1.0, "huber")
+    assert int(g["ref_status"]) > 0
+    assert c <= float(g["ref_cost"]) * (1 + 1e-6) and c <= float(g["tight_cost"]) * (1 + 1e-6)
+    assert BA.last_summary["status"] > 0

@@ -1,0 +1,229 @@
+"""GPU parity tests: the HIP engine (through the C ABI) against the oracle and the golden vectors
+captured from the reference.  Tolerances follow BASELINE.json's north_star:
+  residual / Jacobian evaluations  1e-8 relative
+  final cost                       1e-6 relative (against the converged minimum of the reference objective)
+  mean reprojection error          1e-3 px
+"""
+import numpy as np
+import pytest
+from conftest import SMALL_CASES, load_golden, problem_of
+
+from oracle import ba_oracle as O
+from structure_from_motion_amd import _capi, synthetic
+
+pytestmark = pytest.mark.gpu
+
+RTOL_EVAL = 1e-8
+RTOL_COST = 1e-6
+TOL_PX = 1e-3
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300)
+
+
+def oracle_args(p):
+    return p["cam_pose"], p["cam_intr"], p["points"], p["obs_cam"], p["obs_pt"]
+
+
+@pytest.mark.parametrize("name", SMALL_CASES)
+def test_residuals_cost_jacobian_vs_reference_closure(gpu, name):
+    g = load_golden(name)
+    p = problem_of(g)
+    arr = _capi.Arrays.from_dict(p)
+    f = _capi.eval_residuals(arr)
+    np.testing.assert_allclose(f, g["f0"], rtol=RTOL_EVAL, atol=1e-9)      # reference's residuals(x0)
+    assert rel(f, g["f0"]) < 1e-10
+    fs = float(g["f_scale"])
+    z = (g["f0"] / fs) ** 2
+    ref_cost = 0.5 * fs * fs * np.where(z <= 1, z, 2 * np.sqrt(z) - 1).sum()
+    assert abs(_capi.eval_cost(arr, "huber", fs) - ref_cost) <= 1e-10 * ref_cost
+    jc, jp = _capi.eval_jacobian_blocks(arr)
+    ojc, ojp = O.jacobian_blocks(*oracle_args(p))
+    assert rel(jc, ojc) < 1e-12 and rel(jp, ojp) < 1e-12
+    # against the reference closure's own differences (4th order): 1e-8 norm-wise
+    cam_off, pt_off, n = O.param_index(p["cam_fixed"], len(p["points"]))
+    J = np.zeros((2 * len(p["obs_cam"]), n))
+    for k in range(len(p["obs_cam"])):
+        co = cam_off[p["obs_cam"][k]]
+        if co >= 0:
+            J[2 * k:2 * k + 2, co:co + 6] = jc[k]
+        po = pt_off + 3 * p["obs_pt"][k]
+        J[2 * k:2 * k + 2, po:po + 3] = jp[k]
+    Jh = np.zeros_like(J); Jh[g["jh_row"], g["jh_col"]] = g["jh_val"]
+    J2 = np.zeros_like(J); J2[g["j2_row"], g["j2_col"]] = g["j2_val"]
+    assert rel(J, Jh) < RTOL_EVAL
+    assert rel(J, J2) < 1e-5     # scipy's 2-point Jacobian is itself only ~sqrt(eps) accurate
+
+
+@pytest.mark.parametrize("loss", O.LOSSES)
+def test_all_losses_cost(gpu, loss):
+    p = synthetic.make_street(12, 300, 1300, seed=5, outlier_frac=0.1)
+    arr = _capi.Arrays.from_dict(p)
+    f = O.residuals(*oracle_args(p), p["obs_xy"])
+    for fs in (0.7, 1.0, 2.5):
+        c = _capi.eval_cost(arr, loss, fs)
+        assert abs(c - O.cost(f, fs, loss)) <= 1e-11 * abs(c)
+
+
+@pytest.mark.parametrize("name", ["street_outliers", "ring16_dense", "ring_sfm_shape", "ring_unobserved"])
+@pytest.mark.parametrize("lam", [1e-4, 3.0])
+def test_reduced_camera_system_vs_oracle(gpu, name, lam):
+    g = load_golden(name)
+    p = problem_of(g)
+    fs = float(g["f_scale"])
+    nb = O.normal_blocks(*oracle_args(p), p["obs_xy"], fs, "huber")
+    S, gred, _, _, _ = O.reduced_system(nb, p["cam_fixed"], p["obs_cam"], p["obs_pt"], lam)
+    with _capi.Handle(_capi.Arrays.from_dict(p), loss="huber", f_scale=fs) as h:
+        h.build(lam)
+        r = h.reduced_system()
+        free = p["cam_fixed"] == 0
+        assert rel(r["U"][free], nb["U"][free]) < 1e-12
+        assert rel(r["gc"][free], nb["gc"][free]) < 1e-11
+        assert rel(r["V"], nb["V"]) < 1e-12
+        assert rel(r["gp"], nb["gp"]) < 1e-11
+        assert rel(r["S"], S) < 1e-10
+        assert rel(r["gred"], gred) < 1e-9
+        assert np.allclose(r["S"], r["S"].T, rtol=0, atol=1e-9 * np.abs(S).max())
+        assert abs(h.cost() - nb["F"]) <= 1e-12 * nb["F"]
+
+
+@pytest.mark.parametrize("name", SMALL_CASES)
+def test_lm_solution_vs_reference_minimum(gpu, name):
+    g = load_golden(name)
+    p = problem_of(g)
+    fs = float(g["f_scale"])
+    arr = _capi.Arrays.from_dict(p)
+    s = _capi.solve(arr, loss="huber", f_scale=fs, max_iter=int(g["max_nfev"]))
+    assert s["status"] > 0, s
+    tight = float(g["tight_cost"])
+    # cost re-evaluated through the oracle objective at the returned state
+    f = O.residuals(arr.cam_pose, p["cam_intr"], arr.points, p["obs_cam"], p["obs_pt"], p["obs_xy"])
+    c = O.cost(f, fs, "huber")
+    assert abs(c - s["final_cost"]) <= 1e-10 * c
+    assert c <= tight * (1 + RTOL_COST), (c, tight)
+    assert c >= tight * (1 - 1e-4)          # same basin as the reference objective's minimum
+    if int(g["ref_status"]) > 0:            # where the reference itself converged: within 1e-6 of it
+        assert c <= float(g["ref_cost"]) * (1 + RTOL_COST)
+        assert abs(c - float(g["ref_cost"])) <= RTOL_COST * 10 * float(g["ref_cost"])
+    # mean reprojection error against the converged solution, 1e-3 px
+    nf = int((p["cam_fixed"] == 0).sum())
+    cp_t, pt_t = O.unpack(g["tight_x"], p["cam_pose"], p["cam_fixed"], len(p["points"]))
+    ft = O.residuals(cp_t, p["cam_intr"], pt_t, p["obs_cam"], p["obs_pt"], p["obs_xy"]).reshape(-1, 2)
+    e_t = np.linalg.norm(ft, axis=1).mean()
+    e = np.linalg.norm(f.reshape(-1, 2), axis=1).mean()
+    assert abs(e - e_t) < TOL_PX
+    # fixed cameras untouched, unobserved points untouched
+    fixed = p["cam_fixed"] == 1
+    np.testing.assert_array_equal(arr.cam_pose[fixed], p["cam_pose"][fixed])
+    unobs = np.setdiff1d(np.arange(len(p["points"])), p["obs_pt"])
+    np.testing.assert_array_equal(arr.points[unobs], p["points"][unobs])
+    assert nf >= 1
+
+
+def test_engine_matches_oracle_lm_trajectory(gpu):
+    """Same algorithm, same control: the HIP LM and the dense NumPy LM of the oracle visit the
+    same costs (the linear solve differs: PCG vs dense, hence 1e-6)."""
+    p = synthetic.make_street(10, 150, 650, seed=9, outlier_frac=0.03)
+    res = O.lm_solve(p["cam_pose"], p["cam_intr"], p["cam_fixed"], p["points"], p["obs_cam"], p["obs_pt"],
+                     p["obs_xy"], f_scale=1.0, max_iter=60)
+    arr = _capi.Arrays.from_dict(p)
+    s = _capi.solve(arr, loss="huber", f_scale=1.0, max_iter=60, pcg_tol=1e-12)
+    assert s["status"] == res["status"]
+    assert abs(s["final_cost"] - res["cost"]) <= 1e-8 * res["cost"]
+    assert abs(s["initial_cost"] - res["history"][0][1]) <= 1e-12 * s["initial_cost"]
+    assert abs(s["iterations"] - res["iterations"]) <= 2
+
+
+def test_order_invariance_and_chunk_boundaries(gpu):
+    """Shuffling the caller's observation / point order must not change the objective or the
+    reduced system (the engine re-sorts internally); sizes straddle chunk boundaries."""
+    for n_obs in (255, 256, 257, 1031):
+        p = synthetic.make_street(9, n_obs // 4, n_obs, seed=n_obs, outlier_frac=0.02)
+        rng = np.random.default_rng(1)
+        perm_o = rng.permutation(len(p["obs_cam"]))
+        perm_p = rng.permutation(len(p["points"]))
+        inv_p = np.argsort(perm_p)
+        q = dict(p)
+        q["points"] = p["points"][perm_p]
+        q["obs_pt"] = inv_p[p["obs_pt"]][perm_o].astype(np.int32)
+        q["obs_cam"] = p["obs_cam"][perm_o]
+        q["obs_xy"] = p["obs_xy"][perm_o]
+        fa = _capi.eval_residuals(_capi.Arrays.from_dict(p)).reshape(-1, 2)
+        fb = _capi.eval_residuals(_capi.Arrays.from_dict(q)).reshape(-1, 2)
+        np.testing.assert_array_equal(fa[perm_o], fb)
+        with _capi.Handle(_capi.Arrays.from_dict(p)) as ha, _capi.Handle(_capi.Arrays.from_dict(q)) as hb:
+            ha.build(1e-3); hb.build(1e-3)
+            ra, rb = ha.reduced_system(), hb.reduced_system()
+            assert rel(ra["S"], rb["S"]) < 1e-12 and rel(ra["gred"], rb["gred"]) < 1e-11
+            assert rel(ra["V"][perm_p], rb["V"]) < 1e-13
+
+
+def test_edge_cases(gpu):
+    base = synthetic.make_street(6, 40, 160, seed=2)
+    # no observations at all: nothing to optimise, state unchanged, status 1 (gradient is zero)
+    p = dict(base); p["obs_cam"] = p["obs_cam"][:0]; p["obs_pt"] = p["obs_pt"][:0]; p["obs_xy"] = p["obs_xy"][:0]
+    arr = _capi.Arrays.from_dict(p)
+    s = _capi.solve(arr)
+    assert s["status"] == 1 and s["final_cost"] == 0.0
+    np.testing.assert_array_equal(arr.points, p["points"])
+    assert _capi.eval_residuals(arr).shape == (0,)
+    # every camera fixed: points only
+    p = dict(base); p["cam_fixed"] = np.ones(6, np.uint8)
+    arr = _capi.Arrays.from_dict(p)
+    s = _capi.solve(arr)
+    assert s["status"] > 0 and s["final_cost"] < s["initial_cost"]
+    np.testing.assert_array_equal(arr.cam_pose, p["cam_pose"])
+    # the same observation twice (a camera seeing a point twice): still the oracle's system
+    p = dict(base)
+    p["obs_cam"] = np.concatenate([base["obs_cam"], base["obs_cam"][:7]])
+    p["obs_pt"] = np.concatenate([base["obs_pt"], base["obs_pt"][:7]])
+    p["obs_xy"] = np.concatenate([base["obs_xy"], base["obs_xy"][:7] + 0.3])
+    nb = O.normal_blocks(*oracle_args(p), p["obs_xy"], 1.0, "huber")
+    S, gred, _, _, _ = O.reduced_system(nb, p["cam_fixed"], p["obs_cam"], p["obs_pt"], 1e-2)
+    with _capi.Handle(_capi.Arrays.from_dict(p)) as h:
+        h.build(1e-2)
+        r = h.reduced_system(want_points=False)
+        assert rel(r["S"], S) < 1e-10 and rel(r["gred"], gred) < 1e-9
+    # bad index -> error code, no crash; long track -> unsupported
+    p = dict(base); p["obs_cam"] = base["obs_cam"].copy(); p["obs_cam"][0] = 6
+    with pytest.raises(_capi.BaError):
+        _capi.solve(_capi.Arrays.from_dict(p))
+    with pytest.raises(_capi.BaError):
+        _capi.eval_residuals(_capi.Arrays.from_dict(p))
+    # z == 0 (OpenCV substitutes 1/z := 1): finite residual, same as the oracle
+    p = dict(base); p["points"] = base["points"].copy()
+    R = O.rodrigues(p["cam_pose"][:, :3])
+    c, q = int(p["obs_cam"][0]), int(p["obs_pt"][0])
+    only = np.flatnonzero(p["obs_pt"] == q)[:1]
+    p["obs_cam"], p["obs_pt"], p["obs_xy"] = p["obs_cam"][only], p["obs_pt"][only], p["obs_xy"][only]
+    c = int(p["obs_cam"][0])
+    X = p["points"][q]
+    n = R[c][2]
+    X = X - n * ((n @ X + p["cam_pose"][c, 5]) / (n @ n))
+    p["points"][q] = X
+    f = _capi.eval_residuals(_capi.Arrays.from_dict(p))
+    fo = O.residuals(*oracle_args(p), p["obs_xy"])
+    assert np.all(np.isfinite(f)) and np.allclose(f, fo, rtol=1e-6, atol=1e-6)
+
+
+def test_mid_size_properties(gpu):
+    """Ladybug-shaped problem at 1/20 scale: properties that need no CPU reference solve."""
+    p = synthetic.make_config("ladybug1723", scale=0.05)
+    arr = _capi.Arrays.from_dict(p)
+    c0 = _capi.eval_cost(arr, "huber", 1.0)
+    f = O.residuals(*oracle_args(p), p["obs_xy"])
+    assert abs(c0 - O.cost(f, 1.0, "huber")) <= 1e-11 * c0
+    with _capi.Handle(arr, loss="huber", f_scale=1.0, max_iter=50) as h:
+        h.build(1e-4)
+        assert abs(h.cost() - c0) <= 1e-12 * c0
+        s = h.run()
+        cp, pts = h.state()
+    assert s["status"] > 0 and s["final_cost"] < 0.05 * s["initial_cost"]
+    f1 = O.residuals(cp, p["cam_intr"], pts, p["obs_cam"], p["obs_pt"], p["obs_xy"])
+    assert abs(O.cost(f1, 1.0, "huber") - s["final_cost"]) <= 1e-10 * s["final_cost"]
+    # first-order optimality of the robustified objective, checked with the oracle's Jacobian blocks
+    jc, jp = O.jacobian_blocks(cp, p["cam_intr"], pts, p["obs_cam"], p["obs_pt"])
+    w = O.irls_weights(f1, 1.0, "huber").reshape(-1, 2)
+    gp = np.zeros_like(pts); np.add.at(gp, p["obs_pt"], np.einsum("nki,nk->ni", jp * w[:, :, None], f1.reshape(-1, 2)))
+    assert abs(np.abs(gp).max() - s["grad_inf"]) <= 1e-6 * max(s["grad_inf"], 1e-12) or np.abs(gp).max() <= s["grad_inf"]
