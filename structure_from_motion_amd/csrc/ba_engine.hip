@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -214,6 +215,7 @@ BuildArgs build_args(BaHandle *h) {
     A.dbg_gp = h->dbg_gp.n ? h->dbg_gp.p : nullptr;
     A.state = h->state.p;
     A.loss = h->opt.loss;
+    { const char *ab = getenv("BA_ABLATE"); A.ablate = ab ? atoi(ab) : 0; }
     A.inv_fs2 = 1.0 / (h->opt.f_scale * h->opt.f_scale);
     A.half_fs2 = 0.5 * h->opt.f_scale * h->opt.f_scale;
     return A;
@@ -243,7 +245,7 @@ int do_build(BaHandle *h, bool timed) {
         if ((e = call_coll(h, h->gm2.p, 1, BA_REDUCE_MAX))) return e;
     }
     if (nf > 0)
-        hipLaunchKernelGGL(k_finalize, dim3((nf + 63) / 64), dim3(64), 0, st, nf, h->U, h->gc, h->S, h->diag_slot.p,
+        hipLaunchKernelGGL(k_finalize, dim3((nf + 63) / 64), dim3(64), 0, st, nf, h->U, h->gc, h->gred, h->S, h->diag_slot.p,
                            h->Minv.p, h->cam_gmax.p, h->state.p);
     hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(256), 0, st, nf, h->cam_gmax.p, h->gm2.p + 1);
     hipLaunchKernelGGL(k_state_after_build, dim3(1), dim3(1), 0, st, h->state.p, h->sums, h->gm2.p);

@@ -50,6 +50,7 @@ struct BuildArgs {
     double *dbg_v, *dbg_gp;         // optional [n_pts_obs*6], [n_pts_obs*3]
     const LmState *state;           // lambda is read from here
     int loss;
+    int ablate;  // developer timing switch (results invalid when != 0)
     double inv_fs2, half_fs2;
 };
 
@@ -119,6 +120,7 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build(const BuildArgs A) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) { wJp[0][j] = L.w[0] * L.Jp[0][j]; wJp[1][j] = L.w[1] * L.Jp[1][j]; }
         double *vp = &sP[lp * 9];
+        if (!(A.ablate & 2)) {
         atomicAdd(&vp[0], wJp[0][0] * L.Jp[0][0] + wJp[1][0] * L.Jp[1][0]);
         atomicAdd(&vp[1], wJp[0][0] * L.Jp[0][1] + wJp[1][0] * L.Jp[1][1]);
         atomicAdd(&vp[2], wJp[0][0] * L.Jp[0][2] + wJp[1][0] * L.Jp[1][2]);
@@ -128,6 +130,7 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build(const BuildArgs A) {
         atomicAdd(&vp[6], wJp[0][0] * L.r[0] + wJp[1][0] * L.r[1]);
         atomicAdd(&vp[7], wJp[0][1] * L.r[0] + wJp[1][1] * L.r[1]);
         atomicAdd(&vp[8], wJp[0][2] * L.r[0] + wJp[1][2] * L.r[1]);
+        } else { vp[0] = wJp[0][0]; vp[3] = wJp[0][1]; vp[5] = wJp[1][2]; }
         if (lc != -2) {  // free camera
             double wJc[2][6];
 #pragma unroll
@@ -136,7 +139,8 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build(const BuildArgs A) {
             for (int i = 0; i < 6; ++i)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) W[i * 3 + j] = wJc[0][i] * L.Jp[0][j] + wJc[1][i] * L.Jp[1][j];
-            if (lc >= 0) {
+            if (A.ablate & 4) { sC[lc * 33 + (tid & 31)] = wJc[0][0] + wJc[1][5]; }
+            else if (lc >= 0) {
                 double *cp = &sC[lc * 33];
 #pragma unroll
                 for (int i = 0; i < 6; ++i) {
@@ -229,20 +233,23 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build(const BuildArgs A) {
     // ---- phase 3: Schur-complement blocks, lanes over matrix elements -----------------------
     {
         const long long peb = A.ck_pe[ck];
-        const int nelem = (int)(A.ck_pe[ck + 1] - peb) * 36;
+        const int nelem = (A.ablate & 1) ? 0 : (int)(A.ck_pe[ck + 1] - peb) * 36;
         for (int e = tid; e < nelem; e += CHUNK_OBS) {
             const int q = e / 36, ab = e - q * 36, a = ab / 6, b = ab - a * 6;
             const unsigned ent = A.pair_entries[peb + q];
             const int oi = ent & 255u, oj = (ent >> 8) & 255u, lpi = ent >> 16;
             const double *ti = &sT[oi * 18 + a * 3], *tj = &sT[oj * 18 + b * 3];
             const double val = -(ti[0] * tj[0] + ti[1] * tj[1] + ti[2] * tj[2]);
-            if (lpi < CHUNK_PAIRS) atomicAdd(&sS[lpi * 36 + ab], val);
+            if (A.ablate & 16) sS[(lpi % CHUNK_PAIRS) * 36 + ab] = val;
+            else if (A.ablate & 32) { if (val == 1.2345) sS[0] = val; }
+            else if (lpi < CHUNK_PAIRS) atomicAdd(&sS[lpi * 36 + ab], val);
             else atomicAdd(&A.S[(size_t)A.ck_pair_slot[qb + lpi] * 36 + ab], val);
         }
     }
     __syncthreads();
 
     // ---- phase 4: one flush of the LDS tiles per chunk ----------------------------------------
+    if (A.ablate & 8) return;
     for (int i = tid; i < ncam * 33; i += CHUNK_OBS) {
         const int l = i / 33, k = i - l * 33;
         const size_t f = (size_t)A.ck_cam_list[cb + l];
@@ -305,9 +312,9 @@ __device__ __forceinline__ bool spd6_inverse(const double *__restrict__ Ain, dou
     return true;
 }
 
-__global__ void k_finalize(int nf, const double *__restrict__ U, const double *__restrict__ gc, double *__restrict__ S,
-                           const int *__restrict__ diag_slot, double *__restrict__ Minv, double *__restrict__ cam_gmax,
-                           const LmState *__restrict__ st) {
+__global__ void k_finalize(int nf, const double *__restrict__ U, const double *__restrict__ gc, double *__restrict__ gred,
+                           double *__restrict__ S, const int *__restrict__ diag_slot, double *__restrict__ Minv,
+                           double *__restrict__ cam_gmax, const LmState *__restrict__ st) {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= nf) return;
     const double lam = st->lambda;
@@ -342,9 +349,14 @@ __global__ void k_finalize(int nf, const double *__restrict__ U, const double *_
     }
 #pragma unroll
     for (int k = 0; k < 36; ++k) Minv[(size_t)f * 36 + k] = Mi[k];
+    // g_red = g_c - sum_i T_i u_p: the build kernel accumulated the second term only
     double gm = 0.0;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) gm = fmax(gm, fabs(gc[(size_t)f * 6 + i]));
+    for (int i = 0; i < 6; ++i) {
+        const double g = gc[(size_t)f * 6 + i];
+        gred[(size_t)f * 6 + i] += g;
+        gm = fmax(gm, fabs(g));
+    }
     cam_gmax[f] = gm;
 }
 

@@ -82,8 +82,9 @@ def test_reduced_camera_system_vs_oracle(gpu, name, lam):
         assert rel(r["gc"][free], nb["gc"][free]) < 1e-11
         assert rel(r["V"], nb["V"]) < 1e-12
         assert rel(r["gp"], nb["gp"]) < 1e-11
-        assert rel(r["S"], S) < 1e-10
-        assert rel(r["gred"], gred) < 1e-9
+        # (the oracle inverts V + lambda D with cond ~ 1/lambda for rank-deficient V: 1e-8)
+        assert rel(r["S"], S) < 1e-8
+        assert rel(r["gred"], gred) < 1e-8
         assert np.allclose(r["S"], r["S"].T, rtol=0, atol=1e-9 * np.abs(S).max())
         assert abs(h.cost() - nb["F"]) <= 1e-12 * nb["F"]
 

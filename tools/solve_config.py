@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Developer tool: solve one synthetic config on the GPU with the per-iteration table."""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from structure_from_motion_amd import _capi, synthetic  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("config")
+ap.add_argument("--scale", type=float, default=1.0)
+ap.add_argument("--max-iter", type=int, default=100)
+ap.add_argument("--pcg-tol", type=float, default=1e-8)
+ap.add_argument("--pcg-max-iter", type=int, default=500)
+ap.add_argument("--verbose", type=int, default=2)
+a = ap.parse_args()
+p = synthetic.make_config(a.config, scale=a.scale)
+arr = _capi.Arrays.from_dict(p)
+print(p["name"], _capi.analyze(arr))
+t0 = time.time()
+s = _capi.solve(arr, loss="huber", f_scale=1.0, max_iter=a.max_iter, verbose=a.verbose, pcg_tol=a.pcg_tol,
+                pcg_max_iter=a.pcg_max_iter)
+print(s, f"wall {time.time() - t0:.2f}s")
