@@ -230,21 +230,59 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build(const BuildArgs A) {
     }
     __syncthreads();
 
-    // ---- phase 3: Schur-complement blocks, lanes over matrix elements -----------------------
+    // ---- phase 3: Schur-complement blocks -----------------------------------------------------
+    // The chunk's (observation i, observation j, pair) entries are sorted by pair.  Lane t takes a
+    // contiguous slice of them and one half (3 of 6 rows) of the 6x6 block -T_i T_j^T; the running
+    // half block stays in registers while the pair does not change and is added to the LDS tile
+    // only at a pair boundary.
     {
         const long long peb = A.ck_pe[ck];
-        const int nelem = (A.ablate & 1) ? 0 : (int)(A.ck_pe[ck + 1] - peb) * 36;
-        for (int e = tid; e < nelem; e += CHUNK_OBS) {
-            const int q = e / 36, ab = e - q * 36, a = ab / 6, b = ab - a * 6;
-            const unsigned ent = A.pair_entries[peb + q];
-            const int oi = ent & 255u, oj = (ent >> 8) & 255u, lpi = ent >> 16;
-            const double *ti = &sT[oi * 18 + a * 3], *tj = &sT[oj * 18 + b * 3];
-            const double val = -(ti[0] * tj[0] + ti[1] * tj[1] + ti[2] * tj[2]);
-            if (A.ablate & 16) sS[(lpi % CHUNK_PAIRS) * 36 + ab] = val;
-            else if (A.ablate & 32) { if (val == 1.2345) sS[0] = val; }
-            else if (lpi < CHUNK_PAIRS) atomicAdd(&sS[lpi * 36 + ab], val);
-            else atomicAdd(&A.S[(size_t)A.ck_pair_slot[qb + lpi] * 36 + ab], val);
-        }
+        const int E = (A.ablate & 1) ? 0 : (int)(A.ck_pe[ck + 1] - peb);
+        const int K = (E + (CHUNK_OBS / 2 - 1)) / (CHUNK_OBS / 2);
+        const int half = tid & 1;
+        const int e0 = (tid >> 1) * K;
+        const int e1 = (e0 + K < E) ? e0 + K : E;
+        double acc[18];
+        int cur = -1;
+        auto flush = [&]() {
+            if (cur < CHUNK_PAIRS) {
+                double *d = &sS[cur * 36 + half * 18];
+#pragma unroll
+                for (int k = 0; k < 18; ++k) atomicAdd(&d[k], acc[k]);
+            } else {
+                double *d = &A.S[(size_t)A.ck_pair_slot[qb + cur] * 36 + half * 18];
+#pragma unroll
+                for (int k = 0; k < 18; ++k) atomicAdd(&d[k], acc[k]);
+            }
+        };
+        auto process = [&](unsigned ent) {
+            const int oi = ent & 255u, oj = (ent >> 8) & 255u, lpi = (int)(ent >> 16);
+            if (lpi != cur) {
+                if (cur >= 0) flush();
+                cur = lpi;
+#pragma unroll
+                for (int k = 0; k < 18; ++k) acc[k] = 0.0;
+            }
+            const double *ti = &sT[oi * 18 + half * 9], *tj = &sT[oj * 18];
+            double a9[9], b18[18];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) a9[k] = ti[k];
+#pragma unroll
+            for (int k = 0; k < 18; ++k) b18[k] = tj[k];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 6; ++c)
+                    acc[r * 6 + c] -= a9[r * 3] * b18[c * 3] + a9[r * 3 + 1] * b18[c * 3 + 1] + a9[r * 3 + 2] * b18[c * 3 + 2];
+        };
+        unsigned ents[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ents[i] = (e0 + i < e1) ? A.pair_entries[peb + e0 + i] : 0u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (e0 + i < e1) process(ents[i]);
+        for (int e = e0 + 8; e < e1; ++e) process(A.pair_entries[peb + e]);
+        if (cur >= 0) flush();
     }
     __syncthreads();
 

@@ -97,6 +97,10 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
         s.ck_pt.push_back(next_pt);
         s.ck_cam.push_back((int32_t)s.ck_cam_list.size());
         s.ck_pair.push_back((int32_t)ck_pair_key.size());
+        // entries of a chunk sorted by local pair: a lane walks a contiguous slice and keeps the
+        // running block in registers while the pair does not change
+        std::stable_sort(s.pair_entries.begin() + s.ck_pe.back(), s.pair_entries.end(),
+                         [](uint32_t a, uint32_t b) { return (a >> 16) < (b >> 16); });
         s.ck_pe.push_back((int64_t)s.pair_entries.size());
         s.max_chunk_cams = std::max(s.max_chunk_cams, cur_cams);
         s.max_chunk_pairs = std::max(s.max_chunk_pairs, (int)pair_map.size());
