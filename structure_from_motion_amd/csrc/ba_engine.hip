@@ -131,7 +131,8 @@ struct BaHandle {
     DevBuf<double> intr;
     DevBuf<int> cam_free;
     // observations, chunks
-    DevBuf<int> o_cam, o_pt, ck_obs, ck_pt, ck_cam, ck_cam_list, ck_pair, ck_pair_slot;
+    DevBuf<int> o_cam, o_pt, ck_obs, ck_pt, ck_cam, ck_cam_list, ck_pair, ck_pair_slot, ck_cs;
+    DevBuf<unsigned char> cs_obs;
     DevBuf<short> o_lcam;
     DevBuf<double> o_xy;
     DevBuf<long long> ck_pe;
@@ -143,6 +144,7 @@ struct BaHandle {
     DevBuf<double> Minv, cam_gmax, gm2;
     DevBuf<double> pt_linv, pt_u, ck_cost, ck_gmax, ck_part, cam_part, step_sums, cam_sums;
     DevBuf<double> dbg_v, dbg_gp;
+    DevBuf<unsigned long long> stamps;  // diagnostic (ba_debug_stamps)
     DevBuf<double> px, pr, pz, pp, pq;
     DevBuf<PcgScalars> pcg_sc;
     DevBuf<LmState> state;
@@ -215,7 +217,13 @@ BuildArgs build_args(BaHandle *h) {
     A.dbg_gp = h->dbg_gp.n ? h->dbg_gp.p : nullptr;
     A.state = h->state.p;
     A.loss = h->opt.loss;
-    { const char *ab = getenv("BA_ABLATE"); A.ablate = ab ? atoi(ab) : 0; }
+    A.ck_cs = h->ck_cs.p;
+    A.cs_obs = h->cs_obs.p;
+    {
+        int span = 1;
+        while (span < h->sym.max_track && span < 64) span <<= 1;
+        A.seg_span = span;
+    }
     A.inv_fs2 = 1.0 / (h->opt.f_scale * h->opt.f_scale);
     A.half_fs2 = 0.5 * h->opt.f_scale * h->opt.f_scale;
     return A;
@@ -234,7 +242,12 @@ int do_build(BaHandle *h, bool timed) {
     if (timed) HIPCHK(hipEventRecord(h->ev0, st));
     if (h->n_chunks > 0) {
         BuildArgs A = build_args(h);
-        hipLaunchKernelGGL(k_build, dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, A);
+        if (h->stamps.n) {
+            A.stamps = h->stamps.p;
+            hipLaunchKernelGGL(k_build<true>, dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, A);
+        } else {
+            hipLaunchKernelGGL(k_build<false>, dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, A);
+        }
     }
     if (timed) HIPCHK(hipEventRecord(h->ev1, st));
     hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, h->n_chunks, 1, h->ck_cost.p, h->sums);
@@ -398,6 +411,8 @@ int create_impl(const BaProblem *prob, const BaOptions *opt, BaHandle *h) {
     HIPCHK(h->ck_pt.upload(s.ck_pt, st));
     HIPCHK(h->ck_cam.upload(s.ck_cam, st));
     HIPCHK(h->ck_cam_list.upload(s.ck_cam_list, st));
+    HIPCHK(h->ck_cs.upload(s.ck_cs, st));
+    HIPCHK(h->cs_obs.upload(s.cs_obs, st));
     HIPCHK(h->ck_pair.upload(s.ck_pair, st));
     {
         std::vector<long long> pe(s.ck_pe.begin(), s.ck_pe.end());
@@ -751,6 +766,23 @@ int ba_get_reduced_system(BaHandle *h, double *s_out, double *g_red, double *u, 
         }
     }
     return BA_OK;
+}
+
+// Diagnostic only (not in include/ba_hip.h): one build pass with the stamped kernel variant; out gets
+// 12 s_memtime values per chunk.  Used by tools/stamps.py to see where a chunk spends its cycles.
+int ba_debug_stamps(BaHandle *h, unsigned long long *out, long long capacity) {
+    if (!h || !out) return fail(BA_ERR_INVALID, "null argument");
+    (void)hipSetDevice(h->device);
+    if (capacity < (long long)h->n_chunks * 12) return fail(BA_ERR_INVALID, "stamp buffer too small");
+    HIPCHK(h->stamps.alloc((size_t)h->n_chunks * 12));
+    HIPCHK(hipMemset(h->stamps.p, 0, (size_t)h->n_chunks * 12 * 8));
+    int e = do_build(h, false);
+    if (e == BA_OK && (e = do_build(h, false)) == BA_OK) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpy(out, h->stamps.p, (size_t)h->n_chunks * 12 * 8, hipMemcpyDeviceToHost));
+    }
+    h->stamps.release();
+    return e;
 }
 
 int ba_synchronize(BaHandle *h) {

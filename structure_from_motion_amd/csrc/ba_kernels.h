@@ -42,6 +42,8 @@ struct BuildArgs {
     const double *o_xy;
     const int *cam_free;
     const int *ck_obs, *ck_pt, *ck_cam, *ck_cam_list, *ck_pair, *ck_pair_slot;
+    const int *ck_cs;               // per chunk (n_local_cams + 1) offsets into cs_obs, at ck_cam[ck] + ck
+    const unsigned char *cs_obs;    // per chunk: its observations (chunk-local index) grouped by local camera
     const long long *ck_pe;
     const unsigned *pair_entries;
     double *S, *U, *gc, *gred;      // reduced-system accumulators (zeroed before the launch)
@@ -50,8 +52,9 @@ struct BuildArgs {
     double *dbg_v, *dbg_gp;         // optional [n_pts_obs*6], [n_pts_obs*3]
     const LmState *state;           // lambda is read from here
     int loss;
-    int ablate;  // developer timing switch (results invalid when != 0)
+    int seg_span;                   // power of two >= longest track (<= 64): span of the segmented wave sums
     double inv_fs2, half_fs2;
+    unsigned long long *stamps;     // diagnostic build only
 };
 
 __global__ void k_cam_prep(int n_cams, const double *__restrict__ pose, const double *__restrict__ intr,
@@ -78,29 +81,59 @@ __device__ __forceinline__ double block_max256(double v, double *scratch) {
     return fmax(fmax(scratch[0], scratch[1]), fmax(scratch[2], scratch[3]));
 }
 
+// STAMP = true is a diagnostic build only (tools/stamps.py): thread 0 records s_memtime at the phase
+// boundaries into A.stamps (a buffer nothing else reads); never used by the product path.
+#define BA_STAMP(i)                                                               \
+    do {                                                                          \
+        if (STAMP && tid == 0) A.stamps[(size_t)ck * 12 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+template <bool STAMP>
 __global__ __launch_bounds__(CHUNK_OBS) void k_build(const BuildArgs A) {
-    __shared__ double sT[CHUNK_OBS * 18];     // T = W L^-T per observation (6x3)
-    __shared__ double sP[CHUNK_PTS * 9];      // per point: V(6) g_p(3), then L^-1(6) u(3)
-    __shared__ double sC[CHUNK_CAMS * 33];    // per local camera: U(21) g_c(6) g_red(6)
-    __shared__ double sS[CHUNK_PAIRS * 36];   // per local camera pair: -sum T_i T_j^T
+    __shared__ __attribute__((aligned(16))) double sT[CHUNK_OBS * 18];   // T = W L^-T per observation (6x3)
+    __shared__ __attribute__((aligned(16))) double sP[CHUNK_PTS * 9];    // per point: V(6) g_p(3), then L^-1(6) u(3)
+    __shared__ __attribute__((aligned(16))) double sX[CHUNK_PAIRS * 36]; // per local pair: -sum T_i T_j^T
+    __shared__ __attribute__((aligned(16))) double sC[CHUNK_CAMS * 33];  // per local camera: U(21) g_c(6) g_red part(6)
     __shared__ double sRed[4];
+    __shared__ unsigned char sLp[CHUNK_OBS];                             // local point of each observation
+    __shared__ unsigned char sCs[CHUNK_OBS];                             // observations grouped by local camera
+    __shared__ unsigned char sLc[CHUNK_OBS];                             // local camera of each observation
+    __shared__ int sCsStart[CHUNK_CAMS + 1];
+    // (phase 1 stages sqrt(w) Jc (2x6) and sqrt(w) r (2) per observation in sT, which is idle until phase 2b)
 
-    const int ck = blockIdx.x, tid = threadIdx.x;
+    const int ck = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int ob = A.ck_obs[ck], nobs = A.ck_obs[ck + 1] - ob;
     const int pb = A.ck_pt[ck], npts = A.ck_pt[ck + 1] - pb;
     const int cb = A.ck_cam[ck], ncam = A.ck_cam[ck + 1] - cb;
     const int qb = A.ck_pair[ck], npair = A.ck_pair[ck + 1] - qb;
     const int ntile = npair < CHUNK_PAIRS ? npair : CHUNK_PAIRS;
+    const int csb = cb + ck;
     const double lam = A.state->lambda;
 
+    BA_STAMP(0);
     for (int i = tid; i < npts * 9; i += CHUNK_OBS) sP[i] = 0.0;
+    if (tid < nobs) sCs[tid] = A.cs_obs[ob + tid];
+    if (tid <= ncam) sCsStart[tid] = A.ck_cs[csb + tid];
     for (int i = tid; i < ncam * 33; i += CHUNK_OBS) sC[i] = 0.0;
-    for (int i = tid; i < ntile * 36; i += CHUNK_OBS) sS[i] = 0.0;
+    for (int i = tid; i < ntile * 36; i += CHUNK_OBS) sX[i] = 0.0;
+    // the Schur phase's slice of pair entries: fetched now, used four barriers later
+    const long long peb = A.ck_pe[ck];
+    const int E = (int)(A.ck_pe[ck + 1] - peb);
+    const int K = (E + (CHUNK_OBS / 2 - 1)) / (CHUNK_OBS / 2);
+    const int half = tid & 1;
+    const int e0 = (tid >> 1) * K;
+    const int e1 = (e0 + K < E) ? e0 + K : E;
+    unsigned ents[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ents[i] = (e0 + i < e1) ? A.pair_entries[peb + e0 + i] : 0u;
     __syncthreads();
 
+    BA_STAMP(1);
     // ---- phase 1: one observation per lane ------------------------------------------------
     double W[18];
-    int lp = 0, lc = -2, fcam = -1;
+    double vs[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) vs[k] = 0.0;
+    int lp = 0, lc = -2, fcam = -1, key = -1 - tid;
     double cost_loc = 0.0;
     const bool act = tid < nobs;
     if (act) {
@@ -108,7 +141,10 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build(const BuildArgs A) {
         const int cam = A.o_cam[o];
         const int p = A.o_pt[o];
         lp = p - pb;
+        key = lp;
+        sLp[tid] = (unsigned char)lp;
         lc = A.o_lcam[o];
+        sLc[tid] = (unsigned char)lc;
         CamAux ca;
         load_aux(A.aux, cam, ca);
         const double X0 = A.points[3 * (size_t)p], X1 = A.points[3 * (size_t)p + 1], X2 = A.points[3 * (size_t)p + 2];
@@ -119,18 +155,15 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build(const BuildArgs A) {
         double wJp[2][3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) { wJp[0][j] = L.w[0] * L.Jp[0][j]; wJp[1][j] = L.w[1] * L.Jp[1][j]; }
-        double *vp = &sP[lp * 9];
-        if (!(A.ablate & 2)) {
-        atomicAdd(&vp[0], wJp[0][0] * L.Jp[0][0] + wJp[1][0] * L.Jp[1][0]);
-        atomicAdd(&vp[1], wJp[0][0] * L.Jp[0][1] + wJp[1][0] * L.Jp[1][1]);
-        atomicAdd(&vp[2], wJp[0][0] * L.Jp[0][2] + wJp[1][0] * L.Jp[1][2]);
-        atomicAdd(&vp[3], wJp[0][1] * L.Jp[0][1] + wJp[1][1] * L.Jp[1][1]);
-        atomicAdd(&vp[4], wJp[0][1] * L.Jp[0][2] + wJp[1][1] * L.Jp[1][2]);
-        atomicAdd(&vp[5], wJp[0][2] * L.Jp[0][2] + wJp[1][2] * L.Jp[1][2]);
-        atomicAdd(&vp[6], wJp[0][0] * L.r[0] + wJp[1][0] * L.r[1]);
-        atomicAdd(&vp[7], wJp[0][1] * L.r[0] + wJp[1][1] * L.r[1]);
-        atomicAdd(&vp[8], wJp[0][2] * L.r[0] + wJp[1][2] * L.r[1]);
-        } else { vp[0] = wJp[0][0]; vp[3] = wJp[0][1]; vp[5] = wJp[1][2]; }
+        vs[0] = wJp[0][0] * L.Jp[0][0] + wJp[1][0] * L.Jp[1][0];
+        vs[1] = wJp[0][0] * L.Jp[0][1] + wJp[1][0] * L.Jp[1][1];
+        vs[2] = wJp[0][0] * L.Jp[0][2] + wJp[1][0] * L.Jp[1][2];
+        vs[3] = wJp[0][1] * L.Jp[0][1] + wJp[1][1] * L.Jp[1][1];
+        vs[4] = wJp[0][1] * L.Jp[0][2] + wJp[1][1] * L.Jp[1][2];
+        vs[5] = wJp[0][2] * L.Jp[0][2] + wJp[1][2] * L.Jp[1][2];
+        vs[6] = wJp[0][0] * L.r[0] + wJp[1][0] * L.r[1];
+        vs[7] = wJp[0][1] * L.r[0] + wJp[1][1] * L.r[1];
+        vs[8] = wJp[0][2] * L.r[0] + wJp[1][2] * L.r[1];
         if (lc != -2) {  // free camera
             double wJc[2][6];
 #pragma unroll
@@ -139,16 +172,15 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build(const BuildArgs A) {
             for (int i = 0; i < 6; ++i)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) W[i * 3 + j] = wJc[0][i] * L.Jp[0][j] + wJc[1][i] * L.Jp[1][j];
-            if (A.ablate & 4) { sC[lc * 33 + (tid & 31)] = wJc[0][0] + wJc[1][5]; }
-            else if (lc >= 0) {
-                double *cp = &sC[lc * 33];
+            if (lc >= 0) {
+                // stage sqrt(w) Jc and sqrt(w) r: the per-camera sums are gathered below, without atomics
+                const double s0 = sqrt(L.w[0]), s1 = sqrt(L.w[1]);
+                double *js = &sT[tid * 18];
 #pragma unroll
-                for (int i = 0; i < 6; ++i) {
-#pragma unroll
-                    for (int j = i; j < 6; ++j) atomicAdd(&cp[ut6(i, j)], wJc[0][i] * L.Jc[0][j] + wJc[1][i] * L.Jc[1][j]);
-                    atomicAdd(&cp[21 + i], wJc[0][i] * L.r[0] + wJc[1][i] * L.r[1]);
-                }
-            } else {  // camera without an LDS tile in this chunk: straight to HBM
+                for (int i = 0; i < 6; ++i) { js[i] = s0 * L.Jc[0][i]; js[6 + i] = s1 * L.Jc[1][i]; }
+                js[12] = s0 * L.r[0];
+                js[13] = s1 * L.r[1];
+            } else {  // camera without a local slot in this chunk: straight to HBM
                 fcam = A.cam_free[cam];
                 double *up = &A.U[(size_t)fcam * 21], *gp = &A.gc[(size_t)fcam * 6];
 #pragma unroll
@@ -160,8 +192,72 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build(const BuildArgs A) {
             }
         }
     }
+    BA_STAMP(2);
+    // per-point sums: the observations of a point sit in adjacent lanes -> segmented wave reduction,
+    // then one LDS add per (wave, point) instead of one per observation
+    {
+        for (int s = 1; s < A.seg_span; s <<= 1) {
+            const int k2 = __shfl_down(key, s, 64);
+            const bool ok = (lane + s < 64) && (k2 == key);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const double t = __shfl_down(vs[k], s, 64);
+                if (ok) vs[k] += t;
+            }
+        }
+        const int kprev = __shfl_up(key, 1, 64);
+        if (act && (lane == 0 || kprev != key)) {
+            double *vp = &sP[lp * 9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) atomicAdd(&vp[k], vs[k]);
+        }
+    }
     __syncthreads();
 
+    BA_STAMP(3);
+    // ---- phase 1b: per-camera U = sum Js^T Js, g_c = sum Js^T rs, gathered through the chunk's
+    // camera-sorted observation list: lane = (local camera, row, quarter of its observations)
+    for (int item = tid; item < ncam * 24; item += CHUNK_OBS) {
+        const int l = item / 24, rem = item - l * 24, row = rem >> 2, sl = rem & 3;
+        const int c1 = sCsStart[l + 1];
+        double acc[6], g = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[j] = 0.0;
+        for (int k = sCsStart[l] + sl; k < c1; k += 16) {  // four observations per round, loads issued together
+            const double *js[4];
+            double a0[4], a1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kk = k + 4 * u;
+                js[u] = &sT[(int)sCs[kk < c1 ? kk : c1 - 1] * 18];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double wv = (k + 4 * u < c1) ? 1.0 : 0.0;
+                a0[u] = wv * js[u][row];
+                a1[u] = wv * js[u][6 + row];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc[j] += a0[u] * js[u][j] + a1[u] * js[u][6 + j];
+                g += a0[u] * js[u][12] + a1[u] * js[u][13];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { acc[j] += __shfl_xor(acc[j], 1, 64); acc[j] += __shfl_xor(acc[j], 2, 64); }
+        g += __shfl_xor(g, 1, 64);
+        g += __shfl_xor(g, 2, 64);
+        if (sl == 0) {  // the one owner of these elements: plain stores
+            double *up = &sC[l * 33 + row * 6 - (row * (row - 1)) / 2 - row];
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                if (j >= row) up[j] = acc[j];
+            sC[l * 33 + 21 + row] = g;
+        }
+    }
+
+    BA_STAMP(4);
     // ---- phase 2a: one point per lane: damp, 3x3 Cholesky, inverse factor in registers ------
     double gmax_loc = 0.0;
     if (tid < npts) {
@@ -198,6 +294,7 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build(const BuildArgs A) {
         double *gu = &A.pt_u[(size_t)(pb + tid) * 3];
         gu[0] = u0; gu[1] = u1; gu[2] = u2;
     }
+    BA_STAMP(5);
     {
         const double cs = block_sum256(cost_loc, sRed);
         const double gm = block_max256(gmax_loc, sRed);
@@ -205,48 +302,44 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build(const BuildArgs A) {
     }
     __syncthreads();
 
-    // ---- phase 2b: T = W L^-T, reduced gradient -------------------------------------------
+    BA_STAMP(6);
+    // ---- phase 2b: T = W L^-T into LDS (overwrites the phase-1 staging) ---------------------------
     if (act && lc != -2) {
         const double *vp = &sP[lp * 9];
         const double i00 = vp[0], i10 = vp[1], i11 = vp[2], i20 = vp[3], i21 = vp[4], i22 = vp[5];
         const double u0 = vp[6], u1 = vp[7], u2 = vp[8];
         double *tp = &sT[tid * 18];
-        double gr[6];
+        double t[18];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            const double t0 = W[i * 3] * i00;
-            const double t1 = W[i * 3] * i10 + W[i * 3 + 1] * i11;
-            const double t2 = W[i * 3] * i20 + W[i * 3 + 1] * i21 + W[i * 3 + 2] * i22;
-            tp[i * 3] = t0; tp[i * 3 + 1] = t1; tp[i * 3 + 2] = t2;
-            gr[i] = -(t0 * u0 + t1 * u1 + t2 * u2);
+            t[i * 3] = W[i * 3] * i00;
+            t[i * 3 + 1] = W[i * 3] * i10 + W[i * 3 + 1] * i11;
+            t[i * 3 + 2] = W[i * 3] * i20 + W[i * 3 + 1] * i21 + W[i * 3 + 2] * i22;
         }
-        if (lc >= 0) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) atomicAdd(&sC[lc * 33 + 27 + i], gr[i]);
-        } else {
+        for (int k = 0; k < 18; ++k) tp[k] = t[k];
+        if (lc == -1) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) atomicAdd(&A.gred[(size_t)fcam * 6 + i], gr[i]);
+            for (int i = 0; i < 6; ++i)
+                atomicAdd(&A.gred[(size_t)fcam * 6 + i], -(t[i * 3] * u0 + t[i * 3 + 1] * u1 + t[i * 3 + 2] * u2));
         }
     }
     __syncthreads();
+    BA_STAMP(7);
+    BA_STAMP(8);
 
-    // ---- phase 3: Schur-complement blocks -----------------------------------------------------
+    // ---- phase 3: Schur-complement blocks and reduced gradient ----------------------------------
     // The chunk's (observation i, observation j, pair) entries are sorted by pair.  Lane t takes a
     // contiguous slice of them and one half (3 of 6 rows) of the 6x6 block -T_i T_j^T; the running
     // half block stays in registers while the pair does not change and is added to the LDS tile
-    // only at a pair boundary.
+    // only at a pair boundary.  The self entries (i == j) also carry -T_i u_p of the reduced gradient.
+    // LDS reads of entry k+1 are issued before the arithmetic of entry k.
     {
-        const long long peb = A.ck_pe[ck];
-        const int E = (A.ablate & 1) ? 0 : (int)(A.ck_pe[ck + 1] - peb);
-        const int K = (E + (CHUNK_OBS / 2 - 1)) / (CHUNK_OBS / 2);
-        const int half = tid & 1;
-        const int e0 = (tid >> 1) * K;
-        const int e1 = (e0 + K < E) ? e0 + K : E;
-        double acc[18];
-        int cur = -1;
+        double acc[18], gacc[3];
+        int cur = -1, cur_lc = -1;
         auto flush = [&]() {
             if (cur < CHUNK_PAIRS) {
-                double *d = &sS[cur * 36 + half * 18];
+                double *d = &sX[cur * 36 + half * 18];
 #pragma unroll
                 for (int k = 0; k < 18; ++k) atomicAdd(&d[k], acc[k]);
             } else {
@@ -254,40 +347,62 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build(const BuildArgs A) {
 #pragma unroll
                 for (int k = 0; k < 18; ++k) atomicAdd(&d[k], acc[k]);
             }
-        };
-        auto process = [&](unsigned ent) {
-            const int oi = ent & 255u, oj = (ent >> 8) & 255u, lpi = (int)(ent >> 16);
-            if (lpi != cur) {
-                if (cur >= 0) flush();
-                cur = lpi;
+            if (cur_lc >= 0 && cur_lc < CHUNK_CAMS) {
+                double *d = &sC[cur_lc * 33 + 27 + half * 3];
 #pragma unroll
-                for (int k = 0; k < 18; ++k) acc[k] = 0.0;
+                for (int r = 0; r < 3; ++r) atomicAdd(&d[r], gacc[r]);
             }
-            const double *ti = &sT[oi * 18 + half * 9], *tj = &sT[oj * 18];
-            double a9[9], b18[18];
+        };
+        auto fetch = [&](unsigned ent, double *a9, double *b18, double *u3) {
+            const int oi = ent & 255u, oj = (ent >> 8) & 255u;
+            const double *ti = &sT[oi * 18 + half * 9], *tj = &sT[oj * 18], *uu = &sP[(int)sLp[oi] * 9 + 6];
 #pragma unroll
             for (int k = 0; k < 9; ++k) a9[k] = ti[k];
 #pragma unroll
             for (int k = 0; k < 18; ++k) b18[k] = tj[k];
 #pragma unroll
+            for (int k = 0; k < 3; ++k) u3[k] = uu[k];
+        };
+        auto accumulate = [&](unsigned ent, const double *a9, const double *b18, const double *u3) {
+            const int oi = ent & 255u, oj = (ent >> 8) & 255u, lpi = (int)(ent >> 16);
+            if (lpi != cur) {
+                if (cur >= 0) flush();
+                cur = lpi;
+                cur_lc = -1;
+#pragma unroll
+                for (int k = 0; k < 18; ++k) acc[k] = 0.0;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) gacc[r] = 0.0;
+            }
+#pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int c = 0; c < 6; ++c)
                     acc[r * 6 + c] -= a9[r * 3] * b18[c * 3] + a9[r * 3 + 1] * b18[c * 3 + 1] + a9[r * 3 + 2] * b18[c * 3 + 2];
+            if (oi == oj) {
+                cur_lc = sLc[oi];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) gacc[r] -= a9[r * 3] * u3[0] + a9[r * 3 + 1] * u3[1] + a9[r * 3 + 2] * u3[2];
+            }
         };
-        unsigned ents[8];
+        double ta[2][9], tb[2][18], tu[2][3];
+        fetch(ents[0], ta[0], tb[0], tu[0]);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) ents[i] = (e0 + i < e1) ? A.pair_entries[peb + e0 + i] : 0u;
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (e0 + i < e1) process(ents[i]);
-        for (int e = e0 + 8; e < e1; ++e) process(A.pair_entries[peb + e]);
+        for (int i = 0; i < 8; ++i) {
+            if (i < 7) fetch(ents[i + 1], ta[(i + 1) & 1], tb[(i + 1) & 1], tu[(i + 1) & 1]);
+            if (e0 + i < e1) accumulate(ents[i], ta[i & 1], tb[i & 1], tu[i & 1]);
+        }
+        for (int e = e0 + 8; e < e1; ++e) {
+            const unsigned ent = A.pair_entries[peb + e];
+            fetch(ent, ta[0], tb[0], tu[0]);
+            accumulate(ent, ta[0], tb[0], tu[0]);
+        }
         if (cur >= 0) flush();
     }
     __syncthreads();
 
-    // ---- phase 4: one flush of the LDS tiles per chunk ----------------------------------------
-    if (A.ablate & 8) return;
+    BA_STAMP(9);
+    // ---- phase 4: one flush of the LDS pair tile per chunk ---------------------------------------
     for (int i = tid; i < ncam * 33; i += CHUNK_OBS) {
         const int l = i / 33, k = i - l * 33;
         const size_t f = (size_t)A.ck_cam_list[cb + l];
@@ -298,8 +413,9 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build(const BuildArgs A) {
     }
     for (int i = tid; i < ntile * 36; i += CHUNK_OBS) {
         const int l = i / 36, k = i - l * 36;
-        atomicAdd(&A.S[(size_t)A.ck_pair_slot[qb + l] * 36 + k], sS[i]);
+        atomicAdd(&A.S[(size_t)A.ck_pair_slot[qb + l] * 36 + k], sX[i]);
     }
+    BA_STAMP(10);
 }
 
 // ------------------------------------------------------------------ finalize the reduced system

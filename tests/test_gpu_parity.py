@@ -209,13 +209,13 @@ def test_edge_cases(gpu):
 
 
 def test_mid_size_properties(gpu):
-    """Ladybug-shaped problem at 1/20 scale: properties that need no CPU reference solve."""
-    p = synthetic.make_config("ladybug1723", scale=0.05)
+    """BAL-shaped problem (120 cameras, 36 k observations): properties that need no CPU reference solve."""
+    p = synthetic.make_street(120, 8000, 36000, seed=31)
     arr = _capi.Arrays.from_dict(p)
     c0 = _capi.eval_cost(arr, "huber", 1.0)
     f = O.residuals(*oracle_args(p), p["obs_xy"])
     assert abs(c0 - O.cost(f, 1.0, "huber")) <= 1e-11 * c0
-    with _capi.Handle(arr, loss="huber", f_scale=1.0, max_iter=50) as h:
+    with _capi.Handle(arr, loss="huber", f_scale=1.0, max_iter=100) as h:
         h.build(1e-4)
         assert abs(h.cost() - c0) <= 1e-12 * c0
         s = h.run()

@@ -16,7 +16,11 @@ ap.add_argument("--pcg-tol", type=float, default=1e-8)
 ap.add_argument("--pcg-max-iter", type=int, default=500)
 ap.add_argument("--verbose", type=int, default=2)
 a = ap.parse_args()
-p = synthetic.make_config(a.config, scale=a.scale)
+if a.config.startswith("street:"):
+    nc, npt, no, seed = (int(v) for v in a.config.split(":")[1:])
+    p = synthetic.make_street(nc, npt, no, seed=seed)
+else:
+    p = synthetic.make_config(a.config, scale=a.scale)
 arr = _capi.Arrays.from_dict(p)
 print(p["name"], _capi.analyze(arr))
 t0 = time.time()
