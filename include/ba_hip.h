@@ -80,6 +80,8 @@ typedef struct BaOptions {
     int32_t device;        /* HIP device ordinal; -1 = current device */
     int32_t deterministic; /* reserved (0) */
     int32_t reserved;
+    double curv_floor;     /* Hessian weight of a residual component = max(rho' + 2 rho'' z, curv_floor * rho');
+                              1.0 = plain IRLS, default 0.1 (in (0, 1]) */
 } BaOptions;
 
 /* Result: the fields of scipy's OptimizeResult that the reference reads (:223-230). */

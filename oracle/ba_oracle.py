@@ -130,6 +130,32 @@ def cost(f, f_scale=1.0, kind="huber"):
     return 0.5 * f_scale * f_scale * float(rho.sum())
 
 
+def loss_curvature(z, kind):
+    """rho'(z) + 2 z rho''(z): second derivative of the robustified cost w.r.t. the residual
+    component (what scipy uses as the squared row scale, scipy:_lsq/common.py:720-731)."""
+    z = np.asarray(z, dtype=np.float64)
+    if kind == "linear":
+        return np.ones_like(z)
+    if kind == "huber":
+        return np.where(z <= 1, 1.0, 0.0)
+    if kind == "soft_l1":
+        return (1 + z) ** -1.5
+    if kind == "cauchy":
+        return (1 - z) / (1 + z) ** 2
+    if kind == "arctan":
+        return (1 - 3 * z * z) / (1 + z * z) ** 2
+    raise ValueError(kind)
+
+
+CURV_FLOOR = 0.1  # engine default (BaOptions.curv_floor)
+
+
+def hessian_weights(f, f_scale=1.0, kind="huber", floor=CURV_FLOOR):
+    """Weights of the Gauss-Newton Hessian: max(rho' + 2 rho'' z, floor * rho')."""
+    z = (f / f_scale) ** 2
+    return np.maximum(loss_curvature(z, kind), floor * loss_rho(z, kind)[1])
+
+
 def irls_weights(f, f_scale=1.0, kind="huber"):
     """rho'((f/fs)^2) per component: the IRLS / Gauss-Newton weight of the
     robustified cost (gradient = J^T (w * f), scipy:_lsq/common.py:720-731 for g)."""
@@ -212,24 +238,27 @@ def dense_jacobian(cam_pose, cam_intr, cam_fixed, points, obs_cam, obs_pt):
 D_MIN, D_MAX = 1e-6, 1e32  # clamp of the Marquardt scaling diag(J^T W J)
 
 
-def normal_blocks(cam_pose, cam_intr, points, obs_cam, obs_pt, obs_xy, f_scale, kind):
+def normal_blocks(cam_pose, cam_intr, points, obs_cam, obs_pt, obs_xy, f_scale, kind, floor=CURV_FLOOR):
     """Per-camera U (Nc,6,6), g_c (Nc,6); per-point V (Np,3,3), g_p (Np,3);
-    per-observation W = Jc^T diag(w) Jp (No,6,3); cost F."""
+    per-observation W = Jc^T diag(wh) Jp (No,6,3); cost F.  Gradients use w = rho', Hessian
+    blocks use wh = max(rho' + 2 rho'' z, floor rho')."""
     f = residuals(cam_pose, cam_intr, points, obs_cam, obs_pt, obs_xy)
     w = irls_weights(f, f_scale, kind).reshape(-1, 2)
+    wh = hessian_weights(f, f_scale, kind, floor).reshape(-1, 2)
     r = f.reshape(-1, 2)
     Jc, Jp = jacobian_blocks(cam_pose, cam_intr, points, obs_cam, obs_pt)
     Nc, Np = len(cam_pose), len(points)
     U = np.zeros((Nc, 6, 6)); gc = np.zeros((Nc, 6))
     V = np.zeros((Np, 3, 3)); gp = np.zeros((Np, 3))
-    wJc = Jc * w[:, :, None]
-    wJp = Jp * w[:, :, None]
-    np.add.at(U, obs_cam, np.einsum("nki,nkj->nij", wJc, Jc))
-    np.add.at(gc, obs_cam, np.einsum("nki,nk->ni", wJc, r))
-    np.add.at(V, obs_pt, np.einsum("nki,nkj->nij", wJp, Jp))
-    np.add.at(gp, obs_pt, np.einsum("nki,nk->ni", wJp, r))
-    W = np.einsum("nki,nkj->nij", wJc, Jp)
-    return dict(U=U, gc=gc, V=V, gp=gp, W=W, F=cost(f, f_scale, kind), f=f, w=w, Jc=Jc, Jp=Jp)
+    hJc = Jc * wh[:, :, None]
+    hJp = Jp * wh[:, :, None]
+    wr = w * r
+    np.add.at(U, obs_cam, np.einsum("nki,nkj->nij", hJc, Jc))
+    np.add.at(gc, obs_cam, np.einsum("nki,nk->ni", Jc, wr))
+    np.add.at(V, obs_pt, np.einsum("nki,nkj->nij", hJp, Jp))
+    np.add.at(gp, obs_pt, np.einsum("nki,nk->ni", Jp, wr))
+    W = np.einsum("nki,nkj->nij", hJc, Jp)
+    return dict(U=U, gc=gc, V=V, gp=gp, W=W, F=cost(f, f_scale, kind), f=f, w=w, wh=wh, Jc=Jc, Jp=Jp)
 
 
 def reduced_system(nb, cam_fixed, obs_cam, obs_pt, lam):
@@ -281,16 +310,16 @@ def lm_step(nb, cam_fixed, obs_cam, obs_pt, lam):
 
 def lm_solve(cam_pose, cam_intr, cam_fixed, points, obs_cam, obs_pt, obs_xy,
              f_scale=1.0, kind="huber", max_iter=100, ftol=1e-8, xtol=1e-8, gtol=1e-8,
-             lam0=1e-4, verbose=False):
+             lam0=1e-4, floor_min=CURV_FLOOR, verbose=False):
     """Dense restatement of the engine's Levenberg-Marquardt control (Nielsen damping
     update; termination tests of scipy:_lsq/common.py:705-717 and trf.py:451-459).
     Returns dict(cam_pose, points, cost, status, iterations, history)."""
     cam_fixed = np.asarray(cam_fixed).astype(bool)
     cam_pose = cam_pose.copy(); points = points.copy()
-    lam, nu = lam0, 2.0
+    lam, nu, floor = lam0, 2.0, 1.0
     hist = []
     status, it = 0, 0
-    nb = normal_blocks(cam_pose, cam_intr, points, obs_cam, obs_pt, obs_xy, f_scale, kind)
+    nb = normal_blocks(cam_pose, cam_intr, points, obs_cam, obs_pt, obs_xy, f_scale, kind, floor)
     while it < max_iter:
         gfree = np.concatenate([nb["gc"][~cam_fixed].reshape(-1), nb["gp"].reshape(-1)])
         gnorm = np.abs(gfree).max() if gfree.size else 0.0
@@ -301,7 +330,7 @@ def lm_solve(cam_pose, cam_intr, cam_fixed, points, obs_cam, obs_pt, obs_xy,
         it += 1
         Jd = np.einsum("nij,nj->ni", nb["Jc"], dc[obs_cam]) + np.einsum("nij,nj->ni", nb["Jp"], dp[obs_pt])
         r = nb["f"].reshape(-1, 2)
-        pred = -float((nb["w"] * Jd * (r + 0.5 * Jd)).sum())
+        pred = -float((Jd * (nb["w"] * r + 0.5 * nb["wh"] * Jd)).sum())
         cp_t = cam_pose + dc; pt_t = points + dp
         F_t = cost(residuals(cp_t, cam_intr, pt_t, obs_cam, obs_pt, obs_xy), f_scale, kind)
         dF = nb["F"] - F_t
@@ -316,9 +345,13 @@ def lm_solve(cam_pose, cam_intr, cam_fixed, points, obs_cam, obs_pt, obs_xy,
         if rho > 0 and np.isfinite(F_t):
             cam_pose, points = cp_t, pt_t
             lam *= max(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3); nu = 2.0
-            nb = normal_blocks(cam_pose, cam_intr, points, obs_cam, obs_pt, obs_xy, f_scale, kind)
+            if rho > 0.5 and dF < 0.05 * nb["F"]:
+                floor = max(floor_min, 0.25 * floor)
+            nb = normal_blocks(cam_pose, cam_intr, points, obs_cam, obs_pt, obs_xy, f_scale, kind, floor)
         else:
             lam *= nu; nu *= 2.0
+            floor = min(1.0, 4.0 * floor)
+            nb = normal_blocks(cam_pose, cam_intr, points, obs_cam, obs_pt, obs_xy, f_scale, kind, floor)
         lam = min(max(lam, 1e-12), 1e12)
         if ftol_ok and xtol_ok:
             status = 4; break

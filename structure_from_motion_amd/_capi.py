@@ -44,7 +44,7 @@ class BaOptions(C.Structure):
                 ("ftol", C.c_double), ("xtol", C.c_double), ("gtol", C.c_double),
                 ("lambda0", C.c_double), ("pcg_tol", C.c_double), ("pcg_max_iter", C.c_int32),
                 ("linear_solver", C.c_int32), ("verbose", C.c_int32), ("device", C.c_int32),
-                ("deterministic", C.c_int32), ("reserved", C.c_int32)]
+                ("deterministic", C.c_int32), ("reserved", C.c_int32), ("curv_floor", C.c_double)]
 
 
 class BaSummary(C.Structure):

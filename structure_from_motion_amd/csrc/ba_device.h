@@ -101,9 +101,26 @@ __device__ __forceinline__ void loss_eval(int kind, double z, double &rho, doubl
     }
 }
 
+// rho(z), rho'(z) and the exact second derivative of the robustified cost w.r.t. the residual
+// component, c = rho' + 2 rho'' z (scipy _lsq/least_squares.py:169-205 gives rho''; scipy itself
+// uses c as the row scale J_scale, _lsq/common.py:720-731).
+__device__ __forceinline__ void loss_eval2(int kind, double z, double &rho, double &w, double &c) {
+    switch (kind) {
+        case 0: rho = z; w = 1.0; c = 1.0; break;
+        case 1: { double t = 1.0 + z, st = sqrt(t); rho = 2.0 * (st - 1.0); w = 1.0 / st; c = w / t; } break;
+        case 2:
+            if (z <= 1.0) { rho = z; w = 1.0; c = 1.0; }
+            else { double t = sqrt(z); rho = 2.0 * t - 1.0; w = 1.0 / t; c = 0.0; }
+            break;
+        case 3: { double t = 1.0 / (1.0 + z); rho = log1p(z); w = t; c = (1.0 - z) * t * t; } break;
+        default: { double t = 1.0 / (1.0 + z * z); rho = atan(z); w = t; c = (1.0 - 3.0 * z * z) * t * t; } break;
+    }
+}
+
 struct ObsLin {
     double r[2];      // residual (du, dv)
-    double w[2];      // IRLS weights rho'
+    double w[2];      // gradient weights rho'
+    double wh[2];     // curvature weights max(rho' + 2 rho'' z, floor * rho')
     double rho_sum;   // rho(z_u) + rho(z_v)
     double Jc[2][6];  // d(du,dv)/d(rvec, t)
     double Jp[2][3];  // d(du,dv)/dX
@@ -111,7 +128,7 @@ struct ObsLin {
 
 // Residual + analytic Jacobian blocks of one observation.
 __device__ __forceinline__ void linearize(const CamAux &c, double X0, double X1, double X2, double uo, double vo,
-                                          int loss, double inv_fs2, ObsLin &o) {
+                                          int loss, double inv_fs2, double curv_floor, ObsLin &o) {
     const double Y0 = c.R[0] * X0 + c.R[1] * X1 + c.R[2] * X2;
     const double Y1 = c.R[3] * X0 + c.R[4] * X1 + c.R[5] * X2;
     const double Y2 = c.R[6] * X0 + c.R[7] * X1 + c.R[8] * X2;
@@ -137,9 +154,13 @@ __device__ __forceinline__ void linearize(const CamAux &c, double X0, double X1,
         o.Jc[0][j] = q00 * c.Jl[j] + q01 * c.Jl[3 + j] + q02 * c.Jl[6 + j];
         o.Jc[1][j] = q10 * c.Jl[j] + q11 * c.Jl[3 + j] + q12 * c.Jl[6 + j];
     }
-    double rho0, rho1;
-    loss_eval(loss, o.r[0] * o.r[0] * inv_fs2, rho0, o.w[0]);
-    loss_eval(loss, o.r[1] * o.r[1] * inv_fs2, rho1, o.w[1]);
+    double rho0, rho1, c0, c1;
+    loss_eval2(loss, o.r[0] * o.r[0] * inv_fs2, rho0, o.w[0], c0);
+    loss_eval2(loss, o.r[1] * o.r[1] * inv_fs2, rho1, o.w[1], c1);
+    // Gauss-Newton curvature of the robustified cost, floored at a fraction of the IRLS weight so
+    // that fully down-weighted observations still regularise their point
+    o.wh[0] = fmax(c0, curv_floor * o.w[0]);
+    o.wh[1] = fmax(c1, curv_floor * o.w[1]);
     o.rho_sum = rho0 + rho1;
 }
 

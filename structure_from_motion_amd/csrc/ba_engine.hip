@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/ba_hip.h"
+#include "ba_dense.h"
 #include "ba_kernels.h"
 
 namespace {
@@ -147,6 +148,10 @@ struct BaHandle {
     DevBuf<unsigned long long> stamps;  // diagnostic (ba_debug_stamps)
     DevBuf<double> px, pr, pz, pp, pq;
     DevBuf<PcgScalars> pcg_sc;
+    DevBuf<double> dense_a;          // dense reduced system (small camera counts only)
+    DevBuf<long long> upper_keys;
+    DevBuf<int> dense_info;
+    int dense_fallbacks = 0;
     DevBuf<LmState> state;
     LmState hstate{};
     PcgScalars hpcg{};
@@ -182,6 +187,10 @@ int upload_pattern(BaHandle *h) {
     HIPCHK(h->bsr_row.upload(s.bsr_row, st));
     HIPCHK(h->bsr_col.upload(s.bsr_col, st));
     HIPCHK(h->bsr_src.upload(s.bsr_src, st));
+    {
+        std::vector<long long> keys(s.upper_keys.begin(), s.upper_keys.end());
+        HIPCHK(h->upper_keys.upload(keys, st));
+    }
     const size_t nS = (size_t)h->n_upper * 36, nU = (size_t)nf * 21, ng = (size_t)nf * 6;
     HIPCHK(h->red.alloc(nS + nU + 2 * ng + 4));
     h->S = h->red.p;
@@ -305,13 +314,43 @@ int do_pcg(BaHandle *h, int *iters_out) {
     return BA_OK;
 }
 
+// dense Cholesky solve of S x = -g_red (small systems); *ok = false when S is not positive definite
+int do_dense(BaHandle *h, bool *ok) {
+    hipStream_t st = h->stream;
+    const int n = h->sym.n_free * 6;
+    *ok = true;
+    if (n == 0) return BA_OK;
+    if (h->dense_a.n == 0) {
+        HIPCHK(h->dense_a.alloc((size_t)n * n));
+        HIPCHK(h->dense_info.alloc(1));
+    }
+    HIPCHK(hipMemsetAsync(h->dense_a.p, 0, (size_t)n * n * sizeof(double), st));
+    const int ne = h->n_upper * 36;
+    hipLaunchKernelGGL(k_dense_assemble, dim3((ne + 255) / 256), dim3(256), 0, st, h->n_upper, h->upper_keys.p, h->S, n,
+                       h->dense_a.p);
+    hipLaunchKernelGGL(k_dense_cholesky_solve, dim3(1), dim3(1024), 0, st, n, h->dense_a.p, h->gred, h->px.p,
+                       h->dense_info.p);
+    HIPCHK(hipGetLastError());
+    int info = 0;
+    HIPCHK(hipMemcpyAsync(&info, h->dense_info.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    *ok = (info == 0);
+    return BA_OK;
+}
+
 // one LM trial step from the current (built) state; leaves the decision in h->hstate
 int do_step(BaHandle *h) {
     hipStream_t st = h->stream;
     const Symbolic &s = h->sym;
     int pcg_it = 0;
-    int e = do_pcg(h, &pcg_it);
-    if (e) return e;
+    int e;
+    const int n_red = s.n_free * 6;
+    bool solved = false;
+    if (h->opt.linear_solver != BA_SOLVER_PCG && n_red <= BA_DENSE_MAX) {
+        if ((e = do_dense(h, &solved))) return e;
+        if (!solved) h->dense_fallbacks++;
+    }
+    if (!solved && (e = do_pcg(h, &pcg_it))) return e;
     h->total_pcg += pcg_it;
     if (h->world > 1 && s.n_free > 0 && (e = call_coll(h, h->px.p, (int64_t)s.n_free * 6, BA_BROADCAST0))) return e;
     const int cur = h->cur, tr = cur ^ 1;
@@ -328,6 +367,7 @@ int do_step(BaHandle *h) {
         B.pt_linv = h->pt_linv.p; B.pt_u = h->pt_u.p;
         B.ck_part = h->ck_part.p;
         B.loss = h->opt.loss;
+        B.state = h->state.p;
         B.inv_fs2 = 1.0 / (h->opt.f_scale * h->opt.f_scale);
         B.half_fs2 = 0.5 * h->opt.f_scale * h->opt.f_scale;
         hipLaunchKernelGGL(k_backsub, dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, B);
@@ -365,6 +405,7 @@ int create_impl(const BaProblem *prob, const BaOptions *opt, BaHandle *h) {
     if (o.loss < 0 || o.loss > 4) return fail(BA_ERR_INVALID, "unknown loss");
     if (!(o.lambda0 > 0.0)) o.lambda0 = 1e-4;
     if (!(o.pcg_tol > 0.0)) o.pcg_tol = 1e-8;
+    if (!(o.curv_floor > 0.0) || o.curv_floor > 1.0) o.curv_floor = 0.1;
     h->opt = o;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(BA_ERR_HIP, "no HIP device available");
@@ -441,6 +482,8 @@ int create_impl(const BaProblem *prob, const BaOptions *opt, BaHandle *h) {
     LmState s0{};
     s0.lambda = o.lambda0;
     s0.nu = 2.0;
+    s0.floor = 1.0;
+    s0.floor_min = o.curv_floor;
     h->hstate = s0;
     HIPCHK(hipMemcpyAsync(h->state.p, &s0, sizeof s0, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(h->gm2.p, 0, 2 * sizeof(double), st));
@@ -515,6 +558,7 @@ void ba_default_options(BaOptions *o) {
     o->linear_solver = BA_SOLVER_AUTO;
     o->verbose = 0;
     o->device = -1;
+    o->curv_floor = 0.1;
 }
 
 BaHandle *ba_create(const BaProblem *prob, const BaOptions *opt) {

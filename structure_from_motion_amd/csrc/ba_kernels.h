@@ -31,6 +31,8 @@ struct LmState {
     double dF;
     int accept, status, iter, n_accept;
     int terminate, pad0, pad1, pad2;
+    double floor;     // current curvature floor in [floor_min, 1]: 1 = IRLS (far from the minimum), see k_decide
+    double floor_min;
 };
 
 struct BuildArgs {
@@ -150,36 +152,37 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build(const BuildArgs A) {
         const double X0 = A.points[3 * (size_t)p], X1 = A.points[3 * (size_t)p + 1], X2 = A.points[3 * (size_t)p + 2];
         const double2 xy = reinterpret_cast<const double2 *>(A.o_xy)[o];
         ObsLin L;
-        linearize(ca, X0, X1, X2, xy.x, xy.y, A.loss, A.inv_fs2, L);
+        linearize(ca, X0, X1, X2, xy.x, xy.y, A.loss, A.inv_fs2, A.state->floor, L);
         cost_loc = A.half_fs2 * L.rho_sum;
         double wJp[2][3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { wJp[0][j] = L.w[0] * L.Jp[0][j]; wJp[1][j] = L.w[1] * L.Jp[1][j]; }
+        for (int j = 0; j < 3; ++j) { wJp[0][j] = L.wh[0] * L.Jp[0][j]; wJp[1][j] = L.wh[1] * L.Jp[1][j]; }
         vs[0] = wJp[0][0] * L.Jp[0][0] + wJp[1][0] * L.Jp[1][0];
         vs[1] = wJp[0][0] * L.Jp[0][1] + wJp[1][0] * L.Jp[1][1];
         vs[2] = wJp[0][0] * L.Jp[0][2] + wJp[1][0] * L.Jp[1][2];
         vs[3] = wJp[0][1] * L.Jp[0][1] + wJp[1][1] * L.Jp[1][1];
         vs[4] = wJp[0][1] * L.Jp[0][2] + wJp[1][1] * L.Jp[1][2];
         vs[5] = wJp[0][2] * L.Jp[0][2] + wJp[1][2] * L.Jp[1][2];
-        vs[6] = wJp[0][0] * L.r[0] + wJp[1][0] * L.r[1];
-        vs[7] = wJp[0][1] * L.r[0] + wJp[1][1] * L.r[1];
-        vs[8] = wJp[0][2] * L.r[0] + wJp[1][2] * L.r[1];
+        const double wr0 = L.w[0] * L.r[0], wr1 = L.w[1] * L.r[1];
+        vs[6] = L.Jp[0][0] * wr0 + L.Jp[1][0] * wr1;
+        vs[7] = L.Jp[0][1] * wr0 + L.Jp[1][1] * wr1;
+        vs[8] = L.Jp[0][2] * wr0 + L.Jp[1][2] * wr1;
         if (lc != -2) {  // free camera
             double wJc[2][6];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) { wJc[0][i] = L.w[0] * L.Jc[0][i]; wJc[1][i] = L.w[1] * L.Jc[1][i]; }
+            for (int i = 0; i < 6; ++i) { wJc[0][i] = L.wh[0] * L.Jc[0][i]; wJc[1][i] = L.wh[1] * L.Jc[1][i]; }
 #pragma unroll
             for (int i = 0; i < 6; ++i)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) W[i * 3 + j] = wJc[0][i] * L.Jp[0][j] + wJc[1][i] * L.Jp[1][j];
             if (lc >= 0) {
                 // stage sqrt(w) Jc and sqrt(w) r: the per-camera sums are gathered below, without atomics
-                const double s0 = sqrt(L.w[0]), s1 = sqrt(L.w[1]);
+                const double s0 = sqrt(L.wh[0]), s1 = sqrt(L.wh[1]);
                 double *js = &sT[tid * 18];
 #pragma unroll
                 for (int i = 0; i < 6; ++i) { js[i] = s0 * L.Jc[0][i]; js[6 + i] = s1 * L.Jc[1][i]; }
-                js[12] = s0 * L.r[0];
-                js[13] = s1 * L.r[1];
+                js[12] = wr0 / s0;  // Js^T rs = Jc^T (w r)
+                js[13] = wr1 / s1;
             } else {  // camera without a local slot in this chunk: straight to HBM
                 fcam = A.cam_free[cam];
                 double *up = &A.U[(size_t)fcam * 21], *gp = &A.gc[(size_t)fcam * 6];
@@ -659,6 +662,7 @@ struct BacksubArgs {
     double *ck_part;                // [n_chunks*4]: pred, F_trial, |dp|^2, |x_p|^2
     int loss;
     double inv_fs2, half_fs2;
+    const LmState *state;
 };
 
 __global__ __launch_bounds__(CHUNK_OBS) void k_backsub(const BacksubArgs A) {
@@ -671,7 +675,7 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_backsub(const BacksubArgs A) {
     __syncthreads();
     const bool act = tid < nobs;
     int lp = 0, cam = 0;
-    double r0 = 0, r1 = 0, w0 = 0, w1 = 0, a0 = 0, a1 = 0, Jp[2][3], X0 = 0, X1 = 0, X2 = 0, uo = 0, vo = 0;
+    double r0 = 0, r1 = 0, w0 = 0, w1 = 0, h0 = 0, h1 = 0, a0 = 0, a1 = 0, Jp[2][3], X0 = 0, X1 = 0, X2 = 0, uo = 0, vo = 0;
     if (act) {
         const int o = ob + tid;
         cam = A.o_cam[o];
@@ -683,8 +687,8 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_backsub(const BacksubArgs A) {
         const double2 xy = reinterpret_cast<const double2 *>(A.o_xy)[o];
         uo = xy.x; vo = xy.y;
         ObsLin L;
-        linearize(ca, X0, X1, X2, uo, vo, A.loss, A.inv_fs2, L);
-        r0 = L.r[0]; r1 = L.r[1]; w0 = L.w[0]; w1 = L.w[1];
+        linearize(ca, X0, X1, X2, uo, vo, A.loss, A.inv_fs2, A.state->floor, L);
+        r0 = L.r[0]; r1 = L.r[1]; w0 = L.w[0]; w1 = L.w[1]; h0 = L.wh[0]; h1 = L.wh[1];
 #pragma unroll
         for (int j = 0; j < 3; ++j) { Jp[0][j] = L.Jp[0][j]; Jp[1][j] = L.Jp[1][j]; }
         const int f = A.cam_free[cam];
@@ -695,7 +699,7 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_backsub(const BacksubArgs A) {
                 a0 += L.Jc[0][i] * d; a1 += L.Jc[1][i] * d;
             }
         }
-        const double wa0 = w0 * a0, wa1 = w1 * a1;
+        const double wa0 = h0 * a0, wa1 = h1 * a1;
 #pragma unroll
         for (int j = 0; j < 3; ++j) atomicAdd(&sP[lp * 3 + j], Jp[0][j] * wa0 + Jp[1][j] * wa1);
     }
@@ -724,7 +728,7 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_backsub(const BacksubArgs A) {
         const double d0 = sP[lp * 3], d1 = sP[lp * 3 + 1], d2 = sP[lp * 3 + 2];
         const double jd0 = a0 + Jp[0][0] * d0 + Jp[0][1] * d1 + Jp[0][2] * d2;
         const double jd1 = a1 + Jp[1][0] * d0 + Jp[1][1] * d1 + Jp[1][2] * d2;
-        pred = -(w0 * jd0 * (r0 + 0.5 * jd0) + w1 * jd1 * (r1 + 0.5 * jd1));
+        pred = -(jd0 * (w0 * r0 + 0.5 * h0 * jd0) + jd1 * (w1 * r1 + 0.5 * h1 * jd1));
         double u, v;
         project_only(A.aux_t, cam, X0 + d0, X1 + d1, X2 + d2, u, v);
         const double e0 = u - uo, e1 = v - vo;
@@ -795,9 +799,13 @@ __global__ void k_decide(LmState *st, const double *step, const double *cams, do
         st->lambda *= fmax(1.0 / 3.0, 1.0 - t * t * t);
         st->nu = 2.0;
         st->F = Ft;
+        // curvature floor: plain IRLS weights (floor 1, a majoriser: safe far from the minimum) until the
+        // steps become small and well predicted, then towards the exact curvature rho' + 2 rho'' z
+        if (rho > 0.5 && dF < 0.05 * F) st->floor = fmax(st->floor_min, 0.25 * st->floor);
     } else {
         st->lambda *= st->nu;
         st->nu *= 2.0;
+        st->floor = fmin(1.0, 4.0 * st->floor);
     }
     st->lambda = fmin(fmax(st->lambda, 1e-12), 1e12);
     int term = 0;
@@ -852,7 +860,7 @@ __global__ void k_eval_jacobian(long long n_obs, const double *__restrict__ aux,
     CamAux ca;
     load_aux(aux, obs_cam[o], ca);
     ObsLin L;
-    linearize(ca, points[3 * (size_t)p], points[3 * (size_t)p + 1], points[3 * (size_t)p + 2], 0.0, 0.0, 0, 1.0, L);
+    linearize(ca, points[3 * (size_t)p], points[3 * (size_t)p + 1], points[3 * (size_t)p + 2], 0.0, 0.0, 0, 1.0, 1.0, L);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
 #pragma unroll

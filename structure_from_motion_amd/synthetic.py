@@ -71,11 +71,14 @@ def _finish(rng, cam_pose_gt, cam_intr, points_gt, obs_cam, obs_pt, noise, outli
 
 
 def make_street(n_cams, n_points, n_obs, seed=0, noise=0.5, outlier_frac=0.01, max_track=16,
-                n_fixed=1, sig_r=1e-3, sig_t=1e-2, sig_p_rel=1e-2, point_offset=0, cam_seed=None):
+                n_fixed=2, sig_r=1e-3, sig_t=1e-2, sig_p_rel=1e-2, point_offset=0, cam_seed=None):
     """BAL-shaped problem: cameras on a street trajectory (baseline 1), points in a slab at
     depth 5..50 baselines, each observed by a contiguous window of cameras whose length follows
     2 + Poisson so that the mean track is n_obs / n_points.  ``cam_seed`` fixes the cameras
-    independently of the points (used to generate point shards of one problem per rank)."""
+    independently of the points (used to generate point shards of one problem per rank).
+    The first ``n_fixed`` cameras are gauge anchors; the default 2 removes the scale freedom as well
+    (what the reference does below 15 images, ``BundleAdjustment.py:38``) so the problem has an
+    isolated minimum."""
     rng = np.random.default_rng(seed)
     crng = np.random.default_rng(seed if cam_seed is None else cam_seed)
     max_track = min(max_track, n_cams)

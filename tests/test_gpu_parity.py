@@ -72,7 +72,7 @@ def test_reduced_camera_system_vs_oracle(gpu, name, lam):
     g = load_golden(name)
     p = problem_of(g)
     fs = float(g["f_scale"])
-    nb = O.normal_blocks(*oracle_args(p), p["obs_xy"], fs, "huber")
+    nb = O.normal_blocks(*oracle_args(p), p["obs_xy"], fs, "huber", floor=1.0)  # a fresh handle starts at floor 1
     S, gred, _, _, _ = O.reduced_system(nb, p["cam_fixed"], p["obs_cam"], p["obs_pt"], lam)
     with _capi.Handle(_capi.Arrays.from_dict(p), loss="huber", f_scale=fs) as h:
         h.build(lam)
@@ -180,7 +180,7 @@ def test_edge_cases(gpu):
     p["obs_cam"] = np.concatenate([base["obs_cam"], base["obs_cam"][:7]])
     p["obs_pt"] = np.concatenate([base["obs_pt"], base["obs_pt"][:7]])
     p["obs_xy"] = np.concatenate([base["obs_xy"], base["obs_xy"][:7] + 0.3])
-    nb = O.normal_blocks(*oracle_args(p), p["obs_xy"], 1.0, "huber")
+    nb = O.normal_blocks(*oracle_args(p), p["obs_xy"], 1.0, "huber", floor=1.0)
     S, gred, _, _, _ = O.reduced_system(nb, p["cam_fixed"], p["obs_cam"], p["obs_pt"], 1e-2)
     with _capi.Handle(_capi.Arrays.from_dict(p)) as h:
         h.build(1e-2)
@@ -209,8 +209,10 @@ def test_edge_cases(gpu):
 
 
 def test_mid_size_properties(gpu):
-    """BAL-shaped problem (120 cameras, 36 k observations): properties that need no CPU reference solve."""
-    p = synthetic.make_street(120, 8000, 36000, seed=31)
+    """Ring problem with loop closure (60 cameras, 40 k observations): properties that need no CPU
+    reference solve.  (Long open chains such as the street shapes are too ill-conditioned for a
+    convergence assertion: their low-frequency bending modes cost almost nothing.)"""
+    p = synthetic.make_ring(60, 8000, seed=31, mean_track=5.0, outlier_frac=0.01)
     arr = _capi.Arrays.from_dict(p)
     c0 = _capi.eval_cost(arr, "huber", 1.0)
     f = O.residuals(*oracle_args(p), p["obs_xy"])

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(_capi.BaProblem) == 4 + 4 + 8 + 7 * 8 + 8
-    assert ctypes.sizeof(_capi.BaOptions) == 8 + 6 * 8 + 6 * 4
+    assert ctypes.sizeof(_capi.BaOptions) == 8 + 6 * 8 + 6 * 4 + 8
     assert ctypes.sizeof(_capi.BaSummary) == 16 + 7 * 8 + 16
 
 

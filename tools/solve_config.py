@@ -19,6 +19,9 @@ a = ap.parse_args()
 if a.config.startswith("street:"):
     nc, npt, no, seed = (int(v) for v in a.config.split(":")[1:])
     p = synthetic.make_street(nc, npt, no, seed=seed)
+elif a.config.startswith("ring:"):
+    nc, npt, seed = (int(v) for v in a.config.split(":")[1:])
+    p = synthetic.make_ring(nc, npt, seed=seed, mean_track=5.0, outlier_frac=0.01)
 else:
     p = synthetic.make_config(a.config, scale=a.scale)
 arr = _capi.Arrays.from_dict(p)
