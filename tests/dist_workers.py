@@ -1,0 +1,87 @@
+"""Worker functions for the multi-process tests (spawned with torch.multiprocessing)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _init(rank, world, port):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    return dist
+
+
+def oracle_sharded_step(rank, world, port, out_dir):
+    """CPU: one damped Gauss-Newton step of a point-sharded problem with the oracle's math; the
+    partial reduced systems are summed with a gloo all-reduce exactly as dist.py does on the GPU."""
+    import torch
+    dist = _init(rank, world, port)
+    from oracle import ba_oracle as O
+    from structure_from_motion_amd import synthetic
+    from structure_from_motion_amd.dist import shard_points, union_pattern
+    p = synthetic.make_street(7, 90, 400, seed=4, outlier_frac=0.03)
+    sh, pidx = shard_points(p, rank, world)
+    lam = 1e-3
+    nb = O.normal_blocks(sh["cam_pose"], sh["cam_intr"], sh["points"], sh["obs_cam"], sh["obs_pt"], sh["obs_xy"], 1.0, "huber")
+    S, gred, Vinv, _, _ = O.reduced_system(nb, sh["cam_fixed"], sh["obs_cam"], sh["obs_pt"], 0.0 if False else lam)
+    # reduced_system adds U + lam*D(U) per rank; the engine damps AFTER the all-reduce, so rebuild that way:
+    free = np.flatnonzero(sh["cam_fixed"] == 0)
+    for k, c in enumerate(free):
+        Dc = np.clip(np.diag(nb["U"][c]), O.D_MIN, O.D_MAX)
+        S[6 * k:6 * k + 6, 6 * k:6 * k + 6] -= lam * np.diag(Dc)
+    buf = torch.from_numpy(np.concatenate([S.reshape(-1), gred, nb["U"][free].reshape(-1), [nb["F"]]]))
+    dist.all_reduce(buf)
+    n = S.shape[0]
+    S_all = buf[:n * n].numpy().reshape(n, n).copy()
+    g_all = buf[n * n:n * n + n].numpy().copy()
+    U_all = buf[n * n + n:-1].numpy().reshape(len(free), 6, 6)
+    for k in range(len(free)):
+        S_all[6 * k:6 * k + 6, 6 * k:6 * k + 6] += lam * np.diag(np.clip(np.diag(U_all[k]), O.D_MIN, O.D_MAX))
+    dc_flat = np.linalg.solve(S_all, -g_all)
+    t = torch.from_numpy(dc_flat.copy())
+    dist.broadcast(t, src=0)
+    dc = np.zeros((len(sh["cam_pose"]), 6)); dc[free] = t.numpy().reshape(-1, 6)
+    rhs = nb["gp"].copy()
+    np.add.at(rhs, sh["obs_pt"], np.einsum("nij,ni->nj", nb["W"], dc[sh["obs_cam"]]))
+    dp = -np.einsum("nij,nj->ni", Vinv, rhs)
+    # pattern union (co-visible free-camera pairs) through the same helper the GPU path uses
+    fidx = np.cumsum(sh["cam_fixed"] == 0) - 1
+    pairs = set()
+    for q in range(len(sh["points"])):
+        cs = sorted(fidx[c] for c in sh["obs_cam"][sh["obs_pt"] == q] if sh["cam_fixed"][c] == 0)
+        pairs.update((a, b) for i, a in enumerate(cs) for b in cs[i:])
+    local = np.array(sorted(pairs), dtype=np.int32).reshape(-1, 2)
+
+    def gather(obj):
+        out = [None] * world
+        dist.all_gather_object(out, obj)
+        return out
+    uni = union_pattern(local, gather)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), S=S_all, g=g_all, dc=dc, dp=dp, pidx=pidx, F=float(buf[-1]), uni=uni)
+    dist.destroy_process_group()
+
+
+def engine_sharded_solve(rank, world, port, out_dir):
+    """GPU (one device shared by both ranks): the real engine, point-sharded, collectives through
+    torch.distributed (gloo moves the device buffers here; on a multi-GPU node the same code runs
+    over RCCL)."""
+    import torch
+    dist = _init(rank, world, port)
+    torch.cuda.set_device(0)
+    from structure_from_motion_amd import synthetic
+    from structure_from_motion_amd import dist as badist
+    p = synthetic.make_ring(16, 600, seed=8, mean_track=4.0, outlier_frac=0.02)
+    sh, pidx = badist.shard_points(p, rank, world)
+    h = badist.create_sharded_handle(sh, rank, world, loss="huber", f_scale=1.0, max_iter=80, device=0)
+    s = h.run()
+    cp, pts = h.state()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), cp=cp, pts=pts, pidx=pidx, cost=s["final_cost"], status=s["status"],
+             iters=s["iterations"])
+    h.close()
+    dist.destroy_process_group()
