@@ -146,7 +146,7 @@ struct BaHandle {
     DevBuf<double> pt_linv, pt_u, ck_cost, ck_gmax, ck_part, cam_part, step_sums, cam_sums;
     DevBuf<double> dbg_v, dbg_gp;
     DevBuf<unsigned long long> stamps;  // diagnostic (ba_debug_stamps)
-    DevBuf<double> px, pr, pz, pp, pq;
+    DevBuf<double> px, pr, pz, pp, pq, pqv;  // PCG: x, r, z, p (double-buffered: pp / pq), q = S p
     DevBuf<PcgScalars> pcg_sc;
     DevBuf<double> dense_a;          // dense reduced system (small camera counts only)
     DevBuf<long long> upper_keys;
@@ -206,7 +206,9 @@ int upload_pattern(BaHandle *h) {
 int call_coll(BaHandle *h, void *ptr, int64_t n, int op) {
     if (!h->coll || h->world <= 1) return BA_OK;
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->opt.verbose >= 3) { fprintf(stderr, "[ba_hip r%d] collective op %d n %lld\n", h->rank, op, (long long)n); fflush(stderr); }
     if (h->coll(ptr, n, op, h->coll_user) != 0) return fail(BA_ERR_COMM, "collective callback failed");
+    if (h->opt.verbose >= 3) { fprintf(stderr, "[ba_hip r%d] collective done\n", h->rank); fflush(stderr); }
     return BA_OK;
 }
 
@@ -285,26 +287,25 @@ int read_state(BaHandle *h) {
 // block-Jacobi PCG on S x = -g_red; result in h->px
 int do_pcg(BaHandle *h, int *iters_out) {
     hipStream_t st = h->stream;
-    const int n = h->sym.n_free * 6;
+    const int nf = h->sym.n_free;
     *iters_out = 0;
-    if (n == 0) return BA_OK;
-    const int nb = (n + 255) / 256;
+    if (nf == 0) return BA_OK;
+    const int nb_cam = (nf + 255) / 256, nb_row = (nf + 3) / 4;
     HIPCHK(hipMemsetAsync(h->pcg_sc.p, 0, sizeof(PcgScalars), st));
-    hipLaunchKernelGGL(k_pcg_init, dim3(nb), dim3(256), 0, st, n, h->gred, h->Minv.p, h->px.p, h->pr.p, h->pz.p,
-                       h->pp.p, h->pcg_sc.p);
+    hipLaunchKernelGGL(k_pcg_init, dim3(nb_cam), dim3(256), 0, st, nf, h->gred, h->Minv.p, h->px.p, h->pr.p, h->pz.p,
+                       h->pcg_sc.p);
     const double tol2 = h->opt.pcg_tol * h->opt.pcg_tol;
     const int max_it = h->opt.pcg_max_iter > 0 ? h->opt.pcg_max_iter : 500;
-    const int batch = 12;
+    const int batch = 16;
     int it = 0;
     while (it < max_it) {
         const int end = std::min(max_it, it + batch);
         for (; it < end; ++it) {
-            hipLaunchKernelGGL(k_pcg_spmv, dim3(nb), dim3(256), 0, st, n, it, h->bsr_row.p, h->bsr_col.p, h->bsr_src.p,
-                               h->S, h->pp.p, h->pq.p, h->pcg_sc.p);
-            hipLaunchKernelGGL(k_pcg_update, dim3(nb), dim3(256), 0, st, n, it, h->Minv.p, h->pp.p, h->pq.p, h->px.p,
+            double *p_in = (it & 1) ? h->pq.p : h->pp.p, *p_out = (it & 1) ? h->pp.p : h->pq.p;
+            hipLaunchKernelGGL(k_pcg_a, dim3(nb_row), dim3(256), 0, st, nf, it, tol2, h->bsr_row.p, h->bsr_col.p,
+                               h->bsr_src.p, h->S, h->pz.p, p_in, p_out, h->pqv.p, h->pcg_sc.p);
+            hipLaunchKernelGGL(k_pcg_b, dim3(nb_cam), dim3(256), 0, st, nf, it, h->Minv.p, p_out, h->pqv.p, h->px.p,
                                h->pr.p, h->pz.p, h->pcg_sc.p);
-            hipLaunchKernelGGL(k_pcg_direction, dim3(nb), dim3(256), 0, st, n, it, tol2, h->pq.p, h->pz.p, h->pr.p,
-                               h->pp.p, h->pcg_sc.p);
         }
         HIPCHK(hipMemcpyAsync(&h->hpcg, h->pcg_sc.p, sizeof(PcgScalars), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
@@ -349,6 +350,7 @@ int do_step(BaHandle *h) {
     if (h->opt.linear_solver != BA_SOLVER_PCG && n_red <= BA_DENSE_MAX) {
         if ((e = do_dense(h, &solved))) return e;
         if (!solved) h->dense_fallbacks++;
+        if (h->opt.verbose >= 3) { fprintf(stderr, "[ba_hip r%d] dense solved=%d\n", h->rank, (int)solved); fflush(stderr); }
     }
     if (!solved && (e = do_pcg(h, &pcg_it))) return e;
     h->total_pcg += pcg_it;
@@ -477,6 +479,7 @@ int create_impl(const BaProblem *prob, const BaOptions *opt, BaHandle *h) {
     HIPCHK(h->pz.alloc((size_t)nf * 6));
     HIPCHK(h->pp.alloc((size_t)nf * 6));
     HIPCHK(h->pq.alloc((size_t)nf * 6));
+    HIPCHK(h->pqv.alloc((size_t)nf * 6));
     HIPCHK(h->pcg_sc.alloc(1));
     HIPCHK(h->state.alloc(1));
     LmState s0{};

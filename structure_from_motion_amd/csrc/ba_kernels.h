@@ -518,112 +518,131 @@ __global__ void k_finalize(int nf, const double *__restrict__ U, const double *_
 }
 
 // ------------------------------------------------------------------ PCG on S x = -g_red
-// scalars: rz[3] (rotating), pq[2] (alternating), rn[3] (rotating), bnorm2, done(as double), iters(as double)
+// Block-Jacobi preconditioned CG on the block-sparse reduced camera system, two launches per
+// iteration, every scalar (alpha, beta, convergence) on the device:
+//   k_pcg_a(it): p = z + beta p_old (recomputed on the fly for the gathered columns, p is
+//                double-buffered), q = S p with one wave per block row, pq = p.q
+//   k_pcg_b(it): x += alpha p, r -= alpha q, z = M^-1 r, rz = r.z, rn = r.r   (one lane per camera)
+// rz / rn rotate through three slots and pq through two so that a launch never zeroes a slot that
+// another workgroup of the same launch still reads.
 struct PcgScalars {
     double rz[3], pq[2], rn[3], bnorm2, done, iters, pad;
 };
 
-__global__ void k_pcg_init(int n, const double *__restrict__ gred, const double *__restrict__ Minv, double *__restrict__ x,
-                           double *__restrict__ r, double *__restrict__ z, double *__restrict__ p, PcgScalars *sc) {
+__global__ void k_pcg_init(int nf, const double *__restrict__ gred, const double *__restrict__ Minv, double *__restrict__ x,
+                           double *__restrict__ r, double *__restrict__ z, PcgScalars *sc) {
     __shared__ double red[4];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
     double rz = 0.0, bb = 0.0;
-    if (i < n) {
-        const int f = i / 6, a = i - f * 6;
+    if (f < nf) {
         double rv[6];
 #pragma unroll
-        for (int b = 0; b < 6; ++b) rv[b] = -gred[f * 6 + b];
-        double zz = 0.0;
+        for (int b = 0; b < 6; ++b) rv[b] = -gred[(size_t)f * 6 + b];
 #pragma unroll
-        for (int b = 0; b < 6; ++b) zz += Minv[(size_t)f * 36 + a * 6 + b] * rv[b];
-        x[i] = 0.0; r[i] = rv[a]; z[i] = zz; p[i] = zz;
-        rz = rv[a] * zz; bb = rv[a] * rv[a];
+        for (int a = 0; a < 6; ++a) {
+            double zz = 0.0;
+#pragma unroll
+            for (int b = 0; b < 6; ++b) zz += Minv[(size_t)f * 36 + a * 6 + b] * rv[b];
+            x[(size_t)f * 6 + a] = 0.0;
+            r[(size_t)f * 6 + a] = rv[a];
+            z[(size_t)f * 6 + a] = zz;
+            rz += rv[a] * zz;
+            bb += rv[a] * rv[a];
+        }
     }
     rz = block_sum256(rz, red);
     bb = block_sum256(bb, red);
     if (threadIdx.x == 0) { atomicAdd(&sc->rz[0], rz); atomicAdd(&sc->bnorm2, bb); }
 }
 
-__global__ void k_pcg_spmv(int n, int it, const int *__restrict__ bsr_row, const int *__restrict__ bsr_col,
-                           const int *__restrict__ bsr_src, const double *__restrict__ S, const double *__restrict__ p,
-                           double *__restrict__ q, PcgScalars *sc) {
+__global__ __launch_bounds__(256) void k_pcg_a(int nf, int it, double tol2, const int *__restrict__ bsr_row,
+                                               const int *__restrict__ bsr_col, const int *__restrict__ bsr_src,
+                                               const double *__restrict__ S, const double *__restrict__ z,
+                                               const double *__restrict__ p_in, double *__restrict__ p_out,
+                                               double *__restrict__ q, PcgScalars *sc) {
     __shared__ double red[4];
     if (sc->done != 0.0) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    double pq = 0.0;
-    if (i < n) {
-        const int f = i / 6, a = i - f * 6;
-        double acc = 0.0;
-        for (int k = bsr_row[f]; k < bsr_row[f + 1]; ++k) {
-            const int src = bsr_src[k];
-            const double *blk = &S[(size_t)(src & 0x7fffffff) * 36];
-            const double *pj = &p[(size_t)bsr_col[k] * 6];
-            if (src >= 0) {
+    const double rz_cur = sc->rz[it % 3];
+    if (!(sc->rn[it % 3] > tol2 * sc->bnorm2) && it > 0) {  // converged after iteration it-1 (same test in every workgroup)
+        if (blockIdx.x == 0 && threadIdx.x == 0) { sc->done = 1.0; sc->iters = it; }
+        return;
+    }
+    const double beta = (it > 0 && sc->rz[(it + 2) % 3] > 0.0) ? rz_cur / sc->rz[(it + 2) % 3] : 0.0;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int f = blockIdx.x * 4 + wv;
+    const int a = lane & 7, slot = lane >> 3;
+    double acc = 0.0, pq = 0.0;
+    if (f < nf) {
+        if (a < 6) {
+            for (int k = bsr_row[f] + slot; k < bsr_row[f + 1]; k += 8) {
+                const int src = bsr_src[k];
+                const double *blk = &S[(size_t)(src & 0x7fffffff) * 36];
+                const size_t j6 = (size_t)bsr_col[k] * 6;
+                double pj[6];
 #pragma unroll
-                for (int b = 0; b < 6; ++b) acc += blk[a * 6 + b] * pj[b];
-            } else {
+                for (int b = 0; b < 6; ++b) pj[b] = (it > 0) ? z[j6 + b] + beta * p_in[j6 + b] : z[j6 + b];
+                if (src >= 0) {
 #pragma unroll
-                for (int b = 0; b < 6; ++b) acc += blk[b * 6 + a] * pj[b];
+                    for (int b = 0; b < 6; ++b) acc += blk[a * 6 + b] * pj[b];
+                } else {
+#pragma unroll
+                    for (int b = 0; b < 6; ++b) acc += blk[b * 6 + a] * pj[b];
+                }
             }
         }
-        q[i] = acc;
-        pq = acc * p[i];
+        acc += __shfl_xor(acc, 8, 64);
+        acc += __shfl_xor(acc, 16, 64);
+        acc += __shfl_xor(acc, 32, 64);
+        if (slot == 0 && a < 6) {
+            const size_t i = (size_t)f * 6 + a;
+            const double pn = (it > 0) ? z[i] + beta * p_in[i] : z[i];
+            p_out[i] = pn;
+            q[i] = acc;
+            pq = pn * acc;
+        }
     }
     pq = block_sum256(pq, red);
     if (threadIdx.x == 0) atomicAdd(&sc->pq[it & 1], pq);
 }
 
-__global__ void k_pcg_update(int n, int it, const double *__restrict__ Minv, const double *__restrict__ p,
-                             const double *__restrict__ q, double *__restrict__ x, double *__restrict__ r,
-                             double *__restrict__ z, PcgScalars *sc) {
+__global__ __launch_bounds__(256) void k_pcg_b(int nf, int it, const double *__restrict__ Minv, const double *__restrict__ p,
+                                               const double *__restrict__ q, double *__restrict__ x,
+                                               double *__restrict__ r, double *__restrict__ z, PcgScalars *sc) {
     __shared__ double red[4];
     if (sc->done != 0.0) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
     const double pqv = sc->pq[it & 1];
     const double alpha = (pqv > 0.0) ? sc->rz[it % 3] / pqv : 0.0;
     double rz = 0.0, rn = 0.0;
-    if (i < n) {
-        const int f = i / 6, a = i - f * 6;
+    if (f < nf) {
         double rv[6];
 #pragma unroll
-        for (int b = 0; b < 6; ++b) rv[b] = r[f * 6 + b] - alpha * q[f * 6 + b];
-        double zz = 0.0;
+        for (int b = 0; b < 6; ++b) {
+            const size_t i = (size_t)f * 6 + b;
+            x[i] += alpha * p[i];
+            rv[b] = r[i] - alpha * q[i];
+            r[i] = rv[b];
+            rn += rv[b] * rv[b];
+        }
 #pragma unroll
-        for (int b = 0; b < 6; ++b) zz += Minv[(size_t)f * 36 + a * 6 + b] * rv[b];
-        x[i] += alpha * p[i];
-        z[i] = zz;
-        rz = rv[a] * zz; rn = rv[a] * rv[a];
-        // r[i] is written by k_pcg_direction (other lanes of this camera still read the old r here)
+        for (int a = 0; a < 6; ++a) {
+            double zz = 0.0;
+#pragma unroll
+            for (int b = 0; b < 6; ++b) zz += Minv[(size_t)f * 36 + a * 6 + b] * rv[b];
+            z[(size_t)f * 6 + a] = zz;
+            rz += rv[a] * zz;
+        }
     }
     rz = block_sum256(rz, red);
     rn = block_sum256(rn, red);
     if (threadIdx.x == 0) { atomicAdd(&sc->rz[(it + 1) % 3], rz); atomicAdd(&sc->rn[(it + 1) % 3], rn); }
-}
-
-__global__ void k_pcg_direction(int n, int it, double tol2, const double *__restrict__ q, const double *__restrict__ z,
-                                double *__restrict__ r, double *__restrict__ p, PcgScalars *sc) {
-    if (sc->done != 0.0) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const double rz_old = sc->rz[it % 3], rz_new = sc->rz[(it + 1) % 3];
-    const double pqv = sc->pq[it & 1];
-    const double alpha = (pqv > 0.0) ? rz_old / pqv : 0.0;
-    const double beta = (rz_old > 0.0) ? rz_new / rz_old : 0.0;
-    const double rn = sc->rn[(it + 1) % 3];
-    const double bn = sc->bnorm2;
-    if (i < n) {
-        r[i] -= alpha * q[i];
-        p[i] = z[i] + beta * p[i];
-    }
-    if (i == 0) {
-        // slots nobody reads in this launch
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // slots nobody touches in this launch or the next k_pcg_a
+        sc->pq[(it + 1) & 1] = 0.0;
         sc->rz[(it + 2) % 3] = 0.0;
         sc->rn[(it + 2) % 3] = 0.0;
-        sc->pq[(it + 1) & 1] = 0.0;
         sc->iters = it + 1;
-    }
-    // every block evaluates the same test; the flag only matters for LATER launches
-    if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) {
-        if (!(rn > tol2 * bn) || !(pqv > 0.0)) sc->done = 1.0;
+        if (!(pqv > 0.0)) sc->done = 1.0;  // S p . p <= 0: stop (x keeps the last good iterate)
     }
 }
 

@@ -33,16 +33,24 @@ def make_collective(group=None):
     import torch
     import torch.distributed as dist
 
+    host_staged = dist.get_backend(group) != "nccl"  # e.g. gloo in the single-GPU tests
+
     def coll(ptr, count, op):
-        t = torch.as_tensor(_DevArray(ptr, count), device="cuda")
+        dev = torch.as_tensor(_DevArray(ptr, count), device="cuda")
+        t = dev.cpu() if host_staged else dev
+        _run(t, op)
+        if host_staged:
+            dev.copy_(t)
+        torch.cuda.current_stream().synchronize()
+        return 0
+
+    def _run(t, op):
         if op == _capi.REDUCE_SUM:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         elif op == _capi.REDUCE_MAX:
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         else:
             dist.broadcast(t, src=0, group=group)
-        torch.cuda.current_stream().synchronize()
-        return 0
     return coll
 
 

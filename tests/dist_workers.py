@@ -78,7 +78,8 @@ def engine_sharded_solve(rank, world, port, out_dir):
     from structure_from_motion_amd import dist as badist
     p = synthetic.make_ring(16, 600, seed=8, mean_track=4.0, outlier_frac=0.02)
     sh, pidx = badist.shard_points(p, rank, world)
-    h = badist.create_sharded_handle(sh, rank, world, loss="huber", f_scale=1.0, max_iter=80, device=0)
+    h = badist.create_sharded_handle(sh, rank, world, loss="huber", f_scale=1.0, max_iter=80, device=0,
+                                     verbose=int(os.environ.get("BA_TEST_VERBOSE", "0")))
     s = h.run()
     cp, pts = h.state()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), cp=cp, pts=pts, pidx=pidx, cost=s["final_cost"], status=s["status"],
