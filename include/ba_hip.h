@@ -44,7 +44,7 @@ extern "C" {
 /* loss kinds = what scipy.optimize.least_squares accepts (scipy _lsq/least_squares.py:208-209);
  * the reference only uses 'huber' (BundleAdjustment.py:332, :367). */
 enum { BA_LOSS_LINEAR = 0, BA_LOSS_SOFT_L1 = 1, BA_LOSS_HUBER = 2, BA_LOSS_CAUCHY = 3, BA_LOSS_ARCTAN = 4 };
-enum { BA_SOLVER_AUTO = 0, BA_SOLVER_PCG = 1, BA_SOLVER_DENSE_CHOLESKY = 2 };
+enum { BA_SOLVER_AUTO = 0, BA_SOLVER_PCG = 1, BA_SOLVER_DENSE_CHOLESKY = 2, BA_SOLVER_BANDED_CHOLESKY = 3 };
 enum { BA_MEM_HOST = 0, BA_MEM_DEVICE = 1 };
 enum { BA_REDUCE_SUM = 0, BA_REDUCE_MAX = 1, BA_BROADCAST0 = 2 };
 
@@ -75,7 +75,8 @@ typedef struct BaOptions {
     double lambda0;        /* initial LM damping (default 1e-4) */
     double pcg_tol;        /* relative residual of the reduced-camera-system solve (default 1e-8) */
     int32_t pcg_max_iter;  /* default 500 */
-    int32_t linear_solver; /* BA_SOLVER_* */
+    int32_t linear_solver; /* BA_SOLVER_*: AUTO = dense Cholesky up to 128 free cameras, block-banded Cholesky when
+                              the co-visibility band is <= 20 cameras wide, block-Jacobi PCG otherwise */
     int32_t verbose;       /* 0 silent, 1 summary, 2 per-iteration table (<- verbose, :219) */
     int32_t device;        /* HIP device ordinal; -1 = current device */
     int32_t deterministic; /* reserved (0) */

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/ba_hip.h"
+#include "ba_banded.h"
 #include "ba_dense.h"
 #include "ba_kernels.h"
 
@@ -149,6 +150,8 @@ struct BaHandle {
     DevBuf<double> px, pr, pz, pp, pq, pqv;  // PCG: x, r, z, p (double-buffered: pp / pq), q = S p
     DevBuf<PcgScalars> pcg_sc;
     DevBuf<double> dense_a;          // dense reduced system (small camera counts only)
+    DevBuf<double> band_l, band_y;   // block-banded factor and forward-substitution work vector
+    bool band_attr_set = false;
     DevBuf<long long> upper_keys;
     DevBuf<int> dense_info;
     int dense_fallbacks = 0;
@@ -339,6 +342,37 @@ int do_dense(BaHandle *h, bool *ok) {
     return BA_OK;
 }
 
+// block-banded Cholesky solve of S x = -g_red; *ok = false when S is not positive definite
+int do_banded(BaHandle *h, bool *ok) {
+    hipStream_t st = h->stream;
+    const int N = h->sym.n_free, B = h->sym.band, P = B + 1;
+    *ok = true;
+    if (N == 0) return BA_OK;
+    const size_t nb = (size_t)N * P * 36;
+    if (h->band_l.n != nb) {
+        HIPCHK(h->band_l.alloc(nb));
+        HIPCHK(h->band_y.alloc((size_t)N * 6));
+        if (h->dense_info.n == 0) HIPCHK(h->dense_info.alloc(1));
+    }
+    const size_t lds = ((size_t)P * P * 36 + (size_t)(B > 0 ? B : 1) * 36 + (size_t)P * 6 + 42) * sizeof(double);
+    if (!h->band_attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void *)k_band_cholesky_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        h->band_attr_set = true;
+    }
+    HIPCHK(hipMemsetAsync(h->band_l.p, 0, nb * sizeof(double), st));
+    const int ne = h->n_upper * 36;
+    hipLaunchKernelGGL(k_band_assemble, dim3((ne + 255) / 256), dim3(256), 0, st, h->n_upper, h->upper_keys.p, h->S, B,
+                       h->band_l.p);
+    hipLaunchKernelGGL(k_band_cholesky_solve, dim3(1), dim3(BA_BAND_THREADS), lds, st, N, B, h->band_l.p, h->gred, h->px.p,
+                       h->band_y.p, h->dense_info.p);
+    HIPCHK(hipGetLastError());
+    int info = 0;
+    HIPCHK(hipMemcpyAsync(&info, h->dense_info.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    *ok = (info == 0);
+    return BA_OK;
+}
+
 // one LM trial step from the current (built) state; leaves the decision in h->hstate
 int do_step(BaHandle *h) {
     hipStream_t st = h->stream;
@@ -347,8 +381,13 @@ int do_step(BaHandle *h) {
     int e;
     const int n_red = s.n_free * 6;
     bool solved = false;
-    if (h->opt.linear_solver != BA_SOLVER_PCG && n_red <= BA_DENSE_MAX) {
+    const int ls = h->opt.linear_solver;
+    const bool can_dense = n_red <= BA_DENSE_MAX, can_band = s.band <= BA_BAND_MAX;
+    if ((ls == BA_SOLVER_AUTO || ls == BA_SOLVER_DENSE_CHOLESKY) && can_dense) {
         if ((e = do_dense(h, &solved))) return e;
+        if (!solved) h->dense_fallbacks++;
+    } else if ((ls == BA_SOLVER_AUTO || ls == BA_SOLVER_BANDED_CHOLESKY || ls == BA_SOLVER_DENSE_CHOLESKY) && can_band) {
+        if ((e = do_banded(h, &solved))) return e;
         if (!solved) h->dense_fallbacks++;
         if (h->opt.verbose >= 3) { fprintf(stderr, "[ba_hip r%d] dense solved=%d\n", h->rank, (int)solved); fflush(stderr); }
     }

@@ -211,6 +211,9 @@ void finalize_pattern(Symbolic &s, const std::vector<int64_t> &extra_keys) {
     // full CSR view
     const int nf = s.n_free;
     s.diag_slot.assign(nf, -1);
+    s.band = 0;
+    for (size_t k = 0; k < keys.size(); ++k)
+        s.band = std::max(s.band, (int)(keys[k] & 0xffffffff) - (int)(keys[k] >> 32));
     std::vector<int32_t> rowcnt(nf + 1, 0);
     for (size_t k = 0; k < keys.size(); ++k) {
         int i = (int)(keys[k] >> 32), j = (int)(keys[k] & 0xffffffff);

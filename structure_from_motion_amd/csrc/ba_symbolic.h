@@ -47,6 +47,7 @@ struct Symbolic {
     // reduced camera system pattern
     std::vector<int64_t> upper_keys; // sorted unique (i<<32 | j), i <= j, free-camera indices
     std::vector<int32_t> diag_slot;  // [n_free]
+    int band = 0;                    // half bandwidth of the pattern in blocks: max (j - i)
     std::vector<int32_t> bsr_row;    // [n_free+1] full (both triangles) pattern
     std::vector<int32_t> bsr_col;    // [nnz_full]
     std::vector<int32_t> bsr_src;    // [nnz_full] upper slot; bit 31 set = use the transposed block

@@ -154,6 +154,22 @@ def test_pcg_and_dense_cholesky_agree(gpu):
     assert np.allclose(out["pcg"][1].cam_pose, out["dense_cholesky"][1].cam_pose, atol=1e-4)
 
 
+def test_banded_and_dense_cholesky_agree(gpu):
+    """Street sequence (co-visibility band 15 cameras wide): the block-banded factorisation gives the
+    same LM path as the dense one."""
+    p = synthetic.make_street(90, 2500, 11000, seed=21)
+    out = {}
+    for solver in ("banded_cholesky", "dense_cholesky"):
+        arr = _capi.Arrays.from_dict(p)
+        out[solver] = (_capi.solve(arr, loss="huber", f_scale=1.0, max_iter=25, linear_solver=solver), arr)
+    sb, sd = out["banded_cholesky"][0], out["dense_cholesky"][0]
+    assert sb["pcg_iterations"] == 0 and sd["pcg_iterations"] == 0
+    assert sb["iterations"] == sd["iterations"] and sb["accepted"] == sd["accepted"]
+    assert abs(sb["final_cost"] - sd["final_cost"]) <= 1e-9 * sd["final_cost"]
+    assert sb["final_cost"] < 0.05 * sb["initial_cost"]
+    assert np.allclose(out["banded_cholesky"][1].cam_pose, out["dense_cholesky"][1].cam_pose, rtol=1e-6, atol=1e-7)
+
+
 def test_order_invariance_and_chunk_boundaries(gpu):
     """Shuffling the caller's observation / point order must not change the objective or the
     reduced system (the engine re-sorts internally); sizes straddle chunk boundaries."""
