@@ -349,22 +349,21 @@ int do_banded(BaHandle *h, bool *ok) {
     *ok = true;
     if (N == 0) return BA_OK;
     const size_t nb = (size_t)N * P * 36;
-    if (h->band_l.n != nb) {
-        HIPCHK(h->band_l.alloc(nb));
+    if (h->band_l.n != nb + BA_BAND_PAD) {
+        HIPCHK(h->band_l.alloc(nb + BA_BAND_PAD));
         HIPCHK(h->band_y.alloc((size_t)N * 6));
         if (h->dense_info.n == 0) HIPCHK(h->dense_info.alloc(1));
     }
-    const size_t lds = ((size_t)P * P * 36 + (size_t)(B > 0 ? B : 1) * 36 + (size_t)P * 6 + 42) * sizeof(double);
-    if (!h->band_attr_set) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_band_cholesky_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        h->band_attr_set = true;
-    }
-    HIPCHK(hipMemsetAsync(h->band_l.p, 0, nb * sizeof(double), st));
+    HIPCHK(hipMemsetAsync(h->band_l.p, 0, (nb + BA_BAND_PAD) * sizeof(double), st));
     const int ne = h->n_upper * 36;
     hipLaunchKernelGGL(k_band_assemble, dim3((ne + 255) / 256), dim3(256), 0, st, h->n_upper, h->upper_keys.p, h->S, B,
                        h->band_l.p);
-    hipLaunchKernelGGL(k_band_cholesky_solve, dim3(1), dim3(BA_BAND_THREADS), lds, st, N, B, h->band_l.p, h->gred, h->px.p,
-                       h->band_y.p, h->dense_info.p);
+    hipLaunchKernelGGL(k_band_cholesky_solve, dim3(1), dim3(band_threads(B)), 0, st, N, B, h->band_l.p, h->gred, h->band_y.p,
+                       h->dense_info.p);
+    hipLaunchKernelGGL(k_band_scale, dim3(N), dim3(((B * 6 + 1 + 63) / 64) * 64), 0, st, N, B, h->band_l.p, h->band_y.p,
+                       h->dense_info.p);
+    hipLaunchKernelGGL(k_band_backward, dim3(1), dim3(BA_BAND_BACK_THREADS), 0, st, N, B, h->band_l.p, h->band_y.p, h->px.p,
+                       h->dense_info.p);
     HIPCHK(hipGetLastError());
     int info = 0;
     HIPCHK(hipMemcpyAsync(&info, h->dense_info.p, sizeof(int), hipMemcpyDeviceToHost, st));
