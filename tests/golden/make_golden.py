@@ -156,6 +156,52 @@ def run_case(ref, name, prob, f_scale, max_nfev, visited_perm=None, tight=True, 
           f"nfev {res.nfev} success_flag {ok} ({t_total:.1f}s) -> {os.path.getsize(path) / 1024:.0f} kB")
 
 
+def tight_for_existing(ref, name):
+    """Tight minimum for an existing big fixture (written to <name>_tight.npz): the oracle LM finds it, the
+    REFERENCE closure (captured by a spy that stops before scipy runs) evaluates its cost and gradient."""
+    from scipy.optimize._numdiff import approx_derivative, group_columns
+    from oracle import ba_oracle as O
+    d = np.load(os.path.join(HERE, name + ".npz"))
+    prob = {k: d[k] for k in ("cam_pose", "cam_intr", "points", "obs_cam", "obs_pt", "obs_xy")}
+    cam_ids, visited_ids = [int(c) for c in d["cam_ids"]], [int(c) for c in d["visited_ids"]]
+    cameras, points_3d, observations, _ = to_reference_inputs(prob, cam_ids, visited_ids, np.random.default_rng(99))
+    f_scale = float(d["f_scale"])
+    cap = {}
+
+    class _Captured(Exception):
+        pass
+
+    def spy(fun, x0, **kw):
+        cap["fun"], cap["x0"], cap["kw"] = fun, np.array(x0, copy=True), dict(kw)
+        raise _Captured()
+
+    ref.least_squares = spy
+    try:
+        ref.global_bundle_adjustment(cameras, points_3d, observations, visited_ids, robust_loss="huber",
+                                     loss_f_scale=f_scale, max_nfev=int(d["max_nfev"]), verbose=0)
+    except _Captured:
+        pass
+    fun, sparsity = cap["fun"], cap["kw"]["jac_sparsity"]
+    assert np.array_equal(cap["x0"], d["x0"])
+    groups = group_columns(sparsity)
+    t0 = time.time()
+    lm = O.lm_solve(prob["cam_pose"], prob["cam_intr"], d["cam_fixed"], prob["points"], prob["obs_cam"],
+                    prob["obs_pt"], prob["obs_xy"], f_scale=f_scale, kind="huber", max_iter=400,
+                    ftol=1e-15, xtol=1e-15, gtol=1e-10)
+    xs = O.pack(lm["cam_pose"], d["cam_fixed"], lm["points"])
+    f = fun(xs)
+    z = (f / f_scale) ** 2
+    rho = np.where(z <= 1, z, 2 * np.sqrt(np.maximum(z, 1e-300)) - 1)          # scipy least_squares.py:169-178
+    rho1 = np.where(z <= 1, 1.0, np.maximum(z, 1e-300) ** -0.5)
+    cost = 0.5 * f_scale ** 2 * rho.sum()
+    J = approx_derivative(fun, xs, method="3-point", sparsity=(sparsity, groups))
+    gi = float(np.abs(J.T @ (rho1 * f)).max())
+    np.savez_compressed(os.path.join(HERE, name + "_tight.npz"), tight_x=xs, tight_cost=cost, tight_grad_inf=gi,
+                        tight_iterations=lm["iterations"], tight_status=lm["status"], tight_t=time.time() - t0)
+    print(f"{name}: tight cost {cost:.12e} |g|inf {gi:.2e} (oracle LM {lm['iterations']} its, status {lm['status']}; "
+          f"reference stopped at {float(d['ref_cost']):.12e}) in {time.time() - t0:.0f}s")
+
+
 def marshalling_case(ref):
     """Golden for the image_data marshalling path (a8-a12): run the reference's own
     prepare_* / final_ba / inter_ba on a tuple-dict with stand-in KeyPoint objects."""
@@ -217,10 +263,14 @@ def main():
     ap.add_argument("--temple", action="store_true")
     ap.add_argument("--fountain", action="store_true")
     ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--tight-for", default=None, help="existing fixture name: add <name>_tight.npz")
     args = ap.parse_args()
     ref = load_reference()
     if os.environ.get("GOLDEN_ONLY") == "marshalling":
         marshalling_case(ref)
+        return
+    if args.tight_for:
+        tight_for_existing(ref, args.tight_for)
         return
     if args.temple:
         # full size takes about an hour of single-core Python in the reference; --scale shrinks points /

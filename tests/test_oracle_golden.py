@@ -77,3 +77,23 @@ def test_reprojection_error_formula():
         m = p["obs_cam"] == c
         if m.any():
             assert abs(e[c] - np.linalg.norm(f[m], axis=1).mean()) < 1e-9
+
+
+def test_temple_shaped_fixture_pins_oracle():
+    """Temple-shaped final BA at 15 % scale: f(x0) of the reference closure, and the cost the reference closure
+    gave at the stored minimiser (tests/golden/make_golden.py --tight-for)."""
+    g = load_golden("temple_final_s015")
+    t = load_golden("temple_final_s015_tight")
+    p = problem_of(g)
+    f = O.residuals(p["cam_pose"], p["cam_intr"], p["points"], p["obs_cam"], p["obs_pt"], p["obs_xy"])
+    np.testing.assert_allclose(f, g["f0"], rtol=1e-9, atol=1e-10)
+    cp, pt = O.unpack(t["tight_x"], p["cam_pose"], p["cam_fixed"], len(p["points"]))
+    ft = O.residuals(cp, p["cam_intr"], pt, p["obs_cam"], p["obs_pt"], p["obs_xy"])
+    c = O.cost(ft, float(g["f_scale"]), "huber")
+    assert abs(c - float(t["tight_cost"])) <= 1e-11 * c
+    assert float(t["tight_grad_inf"]) < 1e-5 and c < float(g["ref_cost"])
+    # the reference's own end state: its cost through the oracle objective
+    cr, pr = O.unpack(g["ref_x"], p["cam_pose"], p["cam_fixed"], len(p["points"]))
+    fr = O.residuals(cr, p["cam_intr"], pr, p["obs_cam"], p["obs_pt"], p["obs_xy"])
+    np.testing.assert_allclose(fr, g["ref_fun"], rtol=1e-8, atol=1e-9)
+    assert abs(O.cost(fr, float(g["f_scale"]), "huber") - float(g["ref_cost"])) <= 1e-10 * float(g["ref_cost"])
