@@ -76,7 +76,7 @@ typedef struct BaOptions {
     double pcg_tol;        /* relative residual of the reduced-camera-system solve (default 1e-8) */
     int32_t pcg_max_iter;  /* default 500 */
     int32_t linear_solver; /* BA_SOLVER_*: AUTO = dense Cholesky up to 128 free cameras, block-banded Cholesky when
-                              the co-visibility band is <= 20 cameras wide, block-Jacobi PCG otherwise */
+                              co-visible free cameras are at most 16 apart in camera order, block-Jacobi PCG otherwise */
     int32_t verbose;       /* 0 silent, 1 summary, 2 per-iteration table (<- verbose, :219) */
     int32_t device;        /* HIP device ordinal; -1 = current device */
     int32_t deterministic; /* reserved (0) */

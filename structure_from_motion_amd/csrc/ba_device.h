@@ -167,6 +167,23 @@ __device__ __forceinline__ void linearize(const CamAux &c, double X0, double X1,
 // index of (i,j), i<=j, in a row-major packed upper triangle of a 6x6
 __host__ __device__ __forceinline__ constexpr int ut6(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }
 
+// 1 / sqrt(d) for normal positive d: v_rsq_f64 (about 2^-26 relative) and two Newton steps
+__device__ __forceinline__ double rsqrt_nr(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+    double e = fma(-d * y, y, 1.0);
+    y = fma(0.5 * y, e, y);
+    e = fma(-d * y, y, 1.0);
+    return fma(0.5 * y, e, y);
+}
+// value of another lane through DPP (no LDS traffic): CTRL 0xB1 = quad_perm [1,0,3,2] (lane ^ 1),
+// 0x4E = quad_perm [2,3,0,1] (lane ^ 2), 0x141 = row_half_mirror (lane -> 7 - lane within 8)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);

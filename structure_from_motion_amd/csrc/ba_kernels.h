@@ -112,6 +112,18 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build(const BuildArgs A) {
     const double lam = A.state->lambda;
 
     BA_STAMP(0);
+    // this lane's observation: every global load of phase 1 is issued here, unconditionally (clamped index), so
+    // that the two dependent round trips (index -> camera / point data) overlap the staging below
+    const bool act = tid < nobs;
+    const int oo = ob + (act ? tid : 0);
+    const int cam = A.o_cam[oo];
+    const int p = A.o_pt[oo];
+    const int lc_ld = A.o_lcam[oo];
+    const double2 xy = reinterpret_cast<const double2 *>(A.o_xy)[oo];
+    CamAux ca;
+    load_aux(A.aux, cam, ca);
+    const double X0 = A.points[3 * (size_t)p], X1 = A.points[3 * (size_t)p + 1], X2 = A.points[3 * (size_t)p + 2];
+    const double floor_now = A.state->floor;
     for (int i = tid; i < npts * 9; i += CHUNK_OBS) sP[i] = 0.0;
     if (tid < nobs) sCs[tid] = A.cs_obs[ob + tid];
     if (tid <= ncam) sCsStart[tid] = A.ck_cs[csb + tid];
@@ -137,22 +149,14 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build(const BuildArgs A) {
     for (int k = 0; k < 9; ++k) vs[k] = 0.0;
     int lp = 0, lc = -2, fcam = -1, key = -1 - tid;
     double cost_loc = 0.0;
-    const bool act = tid < nobs;
     if (act) {
-        const int o = ob + tid;
-        const int cam = A.o_cam[o];
-        const int p = A.o_pt[o];
         lp = p - pb;
         key = lp;
         sLp[tid] = (unsigned char)lp;
-        lc = A.o_lcam[o];
+        lc = lc_ld;
         sLc[tid] = (unsigned char)lc;
-        CamAux ca;
-        load_aux(A.aux, cam, ca);
-        const double X0 = A.points[3 * (size_t)p], X1 = A.points[3 * (size_t)p + 1], X2 = A.points[3 * (size_t)p + 2];
-        const double2 xy = reinterpret_cast<const double2 *>(A.o_xy)[o];
         ObsLin L;
-        linearize(ca, X0, X1, X2, xy.x, xy.y, A.loss, A.inv_fs2, A.state->floor, L);
+        linearize(ca, X0, X1, X2, xy.x, xy.y, A.loss, A.inv_fs2, floor_now, L);
         cost_loc = A.half_fs2 * L.rho_sum;
         double wJp[2][3];
 #pragma unroll
@@ -177,12 +181,13 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build(const BuildArgs A) {
                 for (int j = 0; j < 3; ++j) W[i * 3 + j] = wJc[0][i] * L.Jp[0][j] + wJc[1][i] * L.Jp[1][j];
             if (lc >= 0) {
                 // stage sqrt(w) Jc and sqrt(w) r: the per-camera sums are gathered below, without atomics
-                const double s0 = sqrt(L.wh[0]), s1 = sqrt(L.wh[1]);
+                const double q0 = rsqrt_nr(L.wh[0]), q1 = rsqrt_nr(L.wh[1]);  // wh > 0
+                const double s0 = L.wh[0] * q0, s1 = L.wh[1] * q1;
                 double *js = &sT[tid * 18];
 #pragma unroll
                 for (int i = 0; i < 6; ++i) { js[i] = s0 * L.Jc[0][i]; js[6 + i] = s1 * L.Jc[1][i]; }
-                js[12] = wr0 / s0;  // Js^T rs = Jc^T (w r)
-                js[13] = wr1 / s1;
+                js[12] = wr0 * q0;  // Js^T rs = Jc^T (w r)
+                js[13] = wr1 * q1;
             } else {  // camera without a local slot in this chunk: straight to HBM
                 fcam = A.cam_free[cam];
                 double *up = &A.U[(size_t)fcam * 21], *gp = &A.gc[(size_t)fcam * 6];
@@ -248,9 +253,9 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build(const BuildArgs A) {
             }
         }
 #pragma unroll
-        for (int j = 0; j < 6; ++j) { acc[j] += __shfl_xor(acc[j], 1, 64); acc[j] += __shfl_xor(acc[j], 2, 64); }
-        g += __shfl_xor(g, 1, 64);
-        g += __shfl_xor(g, 2, 64);
+        for (int j = 0; j < 6; ++j) { acc[j] += dpp_f64<0xB1>(acc[j]); acc[j] += dpp_f64<0x4E>(acc[j]); }  // quad sums
+        g += dpp_f64<0xB1>(g);
+        g += dpp_f64<0x4E>(g);
         if (sl == 0) {  // the one owner of these elements: plain stores
             double *up = &sC[l * 33 + row * 6 - (row * (row - 1)) / 2 - row];
 #pragma unroll
@@ -277,15 +282,13 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build(const BuildArgs A) {
         const double a00 = v00 + lam * fmin(fmax(v00, BA_D_MIN), BA_D_MAX);
         const double a11 = v11 + lam * fmin(fmax(v11, BA_D_MIN), BA_D_MAX);
         const double a22 = v22 + lam * fmin(fmax(v22, BA_D_MIN), BA_D_MAX);
-        const double l00 = sqrt(a00);
-        const double i00 = 1.0 / l00;
+        // reciprocal square roots (v_rsq_f64 + Newton) instead of sqrt and divide: the chain is serial per lane
+        const double i00 = rsqrt_nr(a00);
         const double l10 = v01 * i00, l20 = v02 * i00;
         // (V + lambda D is positive definite; the floors only guard the rounding of rank-deficient V)
-        const double l11 = sqrt(fmax(a11 - l10 * l10, 1e-15 * a11));
-        const double i11 = 1.0 / l11;
+        const double i11 = rsqrt_nr(fmax(a11 - l10 * l10, 1e-15 * a11));
         const double l21 = (v12 - l20 * l10) * i11;
-        const double l22 = sqrt(fmax(a22 - l20 * l20 - l21 * l21, 1e-15 * a22));
-        const double i22 = 1.0 / l22;
+        const double i22 = rsqrt_nr(fmax(a22 - l20 * l20 - l21 * l21, 1e-15 * a22));
         const double i10 = -l10 * i00 * i11;
         const double i21 = -l21 * i11 * i22;
         const double i20 = -(l20 * i00 + l21 * i10) * i22;
