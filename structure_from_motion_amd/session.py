@@ -1,0 +1,158 @@
+"""Array-native marshalling for the ``inter_ba`` / ``final_ba`` protocol.
+
+The reference rebuilds its observation dicts and the parameter vector with per-element Python loops on
+every call (``BundleAdjustment.py:243-295, 46-65``) and BA is invoked every second image on a growing
+problem (``Reconstruction.py:253-255``).  :class:`BASession` goes from the driver's ``image_data`` tuples
+straight to the ``BaProblem`` arrays with NumPy, caches what cannot change between calls (the keypoint
+coordinates of an image), and writes results back vectorised.  Semantics -- camera order, observation
+order, validity rules, gauge, return values, in-place update of ``image_data`` -- are those of the module
+functions in ``BundleAdjustment.py`` of this package, which the tests compare it against.
+
+Not done yet: keeping the device buffers across calls.  The problem structure changes with every call
+of the incremental driver, so the host symbolic analysis reruns each time; only marshalling is saved.
+"""
+import numpy as np
+
+from . import BundleAdjustment as _ba
+from . import _capi
+from .geometry import matrix_to_rvec, rvec_to_matrix
+
+
+class BASession:
+    def __init__(self):
+        self._kp_xy = {}          # img_id -> (id of the keypoint list, its length, (k, 2) float64 coordinates)
+        self.last_summary = None
+
+    # ------------------------------------------------------------------ marshalling
+    def _keypoints(self, img_id, kp):
+        hit = self._kp_xy.get(img_id)
+        if hit is not None and hit[0] == id(kp) and hit[1] == len(kp):
+            return hit[2]
+        xy = np.array([k.pt for k in kp], dtype=np.float64).reshape(-1, 2)
+        self._kp_xy[img_id] = (id(kp), len(kp), xy)
+        return xy
+
+    def _track_entries(self, img_id, cam_data, n_points):
+        """(keypoint indices, point indices) of one image under the reference's rules (:260-264)."""
+        ref_array, kp = cam_data[3], cam_data[5]
+        if isinstance(ref_array, list) and set(map(type, ref_array)) <= {int}:
+            ref = np.asarray(ref_array, dtype=np.int64)
+            ok = (ref != -1) & (ref >= 0) & (ref < n_points)
+            ok[len(kp):] = False
+            kidx = np.flatnonzero(ok)
+            return kidx, ref[kidx]
+        pairs = list(_ba._valid_track_entries(cam_data, n_points))    # anything unusual: the generic rules
+        if not pairs:
+            return np.zeros(0, np.int64), np.zeros(0, np.int64)
+        a = np.array(pairs, dtype=np.int64)
+        return a[:, 0], a[:, 1]
+
+    def marshal(self, image_data, all_points_3D, visited_ids):
+        """-> (Arrays without gauge, cam_ids, colours (Np, 3) or None).  Same camera / observation order as
+        ``prepare_cameras_from_image_data`` + ``prepare_observations_from_image_data`` + ``_to_arrays``."""
+        pts6 = np.asarray(all_points_3D, dtype=np.float64)
+        if pts6.ndim != 2 or pts6.shape[1] < 3:
+            pts6 = np.array([[p[0], p[1], p[2]] for p in all_points_3D], dtype=np.float64).reshape(-1, 3)
+        points = np.ascontiguousarray(pts6[:, :3])
+        colours = pts6[:, 3:6] if pts6.shape[1] >= 6 else None
+        n_points = len(points)
+        usable = [i for i in visited_ids if i in image_data and len(image_data[i]) >= 6]
+        cam_ids = list(dict.fromkeys(usable))
+        index_of = {cid: i for i, cid in enumerate(cam_ids)}
+        n_c = len(cam_ids)
+        cam_pose, cam_intr = np.empty((n_c, 6)), np.empty((n_c, 4))
+        for i, cid in enumerate(cam_ids):
+            R, t, K = image_data[cid][0], image_data[cid][1], image_data[cid][2]
+            cam_pose[i, :3] = matrix_to_rvec(np.asarray(R, dtype=np.float64))
+            cam_pose[i, 3:] = np.asarray(t, dtype=np.float64).reshape(3)
+            K = np.asarray(K, dtype=np.float64)
+            cam_intr[i] = (K[0, 0], K[1, 1], K[0, 2], K[1, 2])
+        oc, op, oxy = [], [], []
+        for img_id in usable:                         # per occurrence, like the reference's loop (:253)
+            cam_data = image_data[img_id]
+            kidx, pidx = self._track_entries(img_id, cam_data, n_points)
+            if len(kidx):
+                oc.append(np.full(len(kidx), index_of[img_id], dtype=np.int32))
+                op.append(pidx.astype(np.int32))
+                oxy.append(self._keypoints(img_id, cam_data[5])[kidx])
+        obs_cam = np.concatenate(oc) if oc else np.zeros(0, np.int32)
+        obs_pt = np.concatenate(op) if op else np.zeros(0, np.int32)
+        obs_xy = np.concatenate(oxy) if oxy else np.zeros((0, 2))
+        arr = _capi.Arrays(cam_pose, cam_intr, np.zeros(n_c, np.uint8), points, obs_cam, obs_pt, obs_xy)
+        return arr, cam_ids, colours
+
+    # ------------------------------------------------------------------ solves
+    def _solve(self, image_data, all_points_3D, visited_ids, f_scale, max_nfev, verbose, min_obs):
+        arr, cam_ids, colours = self.marshal(image_data, all_points_3D, visited_ids)
+        n_c, n_p, n_o = len(cam_ids), len(arr.points), len(arr.obs_cam)
+        if n_c < 3 or n_p < 10 or n_o < min_obs:
+            print("[BA] Insufficient data for BA" if min_obs else f"[BA] Insufficient data: {n_c} cameras, {n_p} points")
+            return all_points_3D, image_data, False
+        print(f"[BA] Starting BA with {n_c} cameras, {n_p} points, {n_o} observations")
+        first_id, second_id, anchor_second = _ba._anchor_ids(cam_ids, visited_ids)
+        fixed_ids = {first_id, second_id} if anchor_second else {first_id}
+        for i, cid in enumerate(cam_ids):
+            arr.cam_fixed[i] = cid in fixed_ids
+        try:
+            if n_o and (arr.obs_pt.min() < 0 or arr.obs_pt.max() >= n_p):
+                raise KeyError(int(arr.obs_pt.max()))
+            s = _capi.solve(arr, loss="huber", f_scale=float(f_scale), max_iter=int(max_nfev),
+                            ftol=1e-8, xtol=1e-8, gtol=1e-8, verbose=2 if verbose else 0)
+            self.last_summary = _ba.last_summary = s
+            if not (s["status"] > 0 or s["final_cost"] < s["residual_sum"] * 0.95):
+                if verbose:
+                    print(f"[BA] Bundle adjustment failed: status {s['status']} after {s['iterations']} steps")
+                return all_points_3D, image_data, False
+            R_new = rvec_to_matrix(arr.cam_pose[:, :3])
+            for i, cid in enumerate(cam_ids):         # in-place update of the tuples (:298-306); anchors keep theirs
+                entry = list(image_data[cid])
+                if cid in fixed_ids:
+                    entry[0] = np.asarray(entry[0]).astype(np.float64)
+                    entry[1] = np.asarray(entry[1]).astype(np.float64).reshape(3, 1)
+                else:
+                    entry[0], entry[1] = R_new[i].copy(), arr.cam_pose[i, 3:].reshape(3, 1).copy()
+                image_data[cid] = tuple(entry)
+            if colours is not None:
+                new_points = np.concatenate([arr.points, colours], axis=1).tolist()
+            else:
+                new_points = [[x, y, z] + list(p[3:6]) for (x, y, z), p in zip(arr.points.tolist(), all_points_3D)]
+            return new_points, image_data, True
+        except Exception as e:                        # as the reference: any failure -> (inputs, False) (:238-240)
+            print(f"[BA] Bundle adjustment error: {e}")
+            return all_points_3D, image_data, False
+
+    def inter_ba(self, image_data, all_points_3D, visited_ids, ba_interval=10, verbose=True):
+        """As ``inter_ba`` (``BundleAdjustment.py:309-350``): huber, f_scale 1.5, max_nfev 150."""
+        if len(visited_ids) % ba_interval != 0 or len(visited_ids) < 3:
+            return all_points_3D, image_data, False
+        return self._solve(image_data, all_points_3D, visited_ids, 1.5, 150, verbose, min_obs=20)
+
+    def final_ba(self, image_data, all_points_3D, visited_ids, verbose=True):
+        """As ``final_ba`` (``BundleAdjustment.py:353-385``): huber, f_scale 1.0, max_nfev 300."""
+        return self._solve(image_data, all_points_3D, visited_ids, 1.0, 300, verbose, min_obs=0)
+
+    # ------------------------------------------------------------------ opt-in step next to the path (8(f) f4)
+    def cull_points(self, image_data, all_points_3D, visited_ids, max_error_px, min_track=1):
+        """Post-BA filtering (NOT reference behaviour -- the reference keeps every point; opt-in only):
+        un-reference every point whose worst reprojection error exceeds ``max_error_px`` or that is seen by
+        fewer than ``min_track`` registered images.  Point indices stay valid: the point row is kept, its
+        entries in the images' reference arrays become -1, so later BA calls pass it through untouched.
+        Errors come from the engine's residual kernel (``ba_eval_residuals``).  Returns the culled indices."""
+        arr, cam_ids, _ = self.marshal(image_data, all_points_3D, visited_ids)
+        if len(arr.obs_cam) == 0:
+            return np.zeros(0, np.int64)
+        err = np.linalg.norm(_capi.eval_residuals(arr).reshape(-1, 2), axis=1)
+        n_p = len(arr.points)
+        worst = np.zeros(n_p)
+        np.maximum.at(worst, arr.obs_pt, err)
+        track = np.bincount(arr.obs_pt, minlength=n_p)
+        bad = np.flatnonzero((track > 0) & ((worst > max_error_px) | (track < min_track)))
+        if len(bad):
+            is_bad = np.zeros(n_p, dtype=bool)
+            is_bad[bad] = True
+            for cid in cam_ids:
+                ref = image_data[cid][3]
+                for k, r in enumerate(ref):
+                    if isinstance(r, int) and 0 <= r < n_p and is_bad[r]:
+                        ref[k] = -1
+        return bad

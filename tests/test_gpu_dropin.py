@@ -89,3 +89,44 @@ def test_global_ba_containers_and_gauge(gpu):
     assert int(g["ref_status"]) > 0
     assert c <= float(g["ref_cost"]) * (1 + 1e-6) and c <= float(g["tight_cost"]) * (1 + 1e-6)
     assert BA.last_summary["status"] > 0
+
+
+def test_session_path_equals_module_functions(gpu):
+    """BASession.final_ba / inter_ba return what the module functions return."""
+    from structure_from_motion_amd.session import BASession
+    g = load_golden("marshalling")
+    ids, image_data, pts = _image_data_from_golden(g)
+    sess = BASession()
+    for name, kw in (("final_ba", {}), ("inter_ba", {"ba_interval": 2})):
+        d1, d2 = copy.deepcopy(image_data), copy.deepcopy(image_data)
+        p1, o1, ok1 = getattr(BA, name)(d1, pts, ids, verbose=False, **kw)
+        p2, o2, ok2 = getattr(sess, name)(d2, pts, ids, verbose=False, **kw)
+        assert ok1 is True and ok2 is True and o2 is d2
+        np.testing.assert_allclose(np.array(p2), np.array(p1), rtol=0, atol=1e-7)
+        assert [p[3:] for p in p2] == [list(p[3:]) for p in pts]          # colours preserved
+        for cid in ids:
+            np.testing.assert_allclose(d2[cid][0], d1[cid][0], rtol=0, atol=1e-8)
+            np.testing.assert_allclose(d2[cid][1], d1[cid][1], rtol=0, atol=1e-7)
+            assert d2[cid][0].dtype == np.float64 and d2[cid][1].shape == (3, 1)
+            assert d2[cid][3] is image_data[cid][3] or d2[cid][3] == image_data[cid][3]
+    assert sess.last_summary["status"] > 0
+
+
+def test_opt_in_point_culling(gpu):
+    """SURVEY 8(f) f4 (opt-in, not reference behaviour): a grossly wrong observation un-references its point."""
+    from structure_from_motion_amd.session import BASession
+    g = load_golden("marshalling")
+    ids, image_data, pts = _image_data_from_golden(g)
+    sess = BASession()
+    assert len(sess.cull_points(image_data, pts, ids, max_error_px=1e4)) == 0
+    k = next(i for i, r in enumerate(image_data[ids[2]][3]) if r != -1)
+    victim = image_data[ids[2]][3][k]
+    image_data[ids[2]][5][k].pt = (image_data[ids[2]][5][k].pt[0] + 500.0, image_data[ids[2]][5][k].pt[1])
+    sess = BASession()                                                    # (keypoints changed: fresh cache)
+    before = sum(r != -1 for c in ids for r in image_data[c][3])
+    bad = sess.cull_points(image_data, pts, ids, max_error_px=100.0)
+    assert bad.tolist() == [victim]
+    assert all(r != victim for c in ids for r in image_data[c][3])
+    assert sum(r != -1 for c in ids for r in image_data[c][3]) < before
+    pts2, d2, ok = sess.final_ba(image_data, pts, ids, verbose=False)
+    assert ok is True and pts2[victim][:3] == pts[victim][:3]             # unobserved point passes through

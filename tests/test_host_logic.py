@@ -154,6 +154,44 @@ def test_marshalling_matches_reference_order_and_types():
     assert out is image_data and np.array_equal(image_data[ids[1]][0], np.eye(3)) and 4242 not in image_data
 
 
+def test_session_marshalling_equals_the_dict_protocol():
+    """the array-native path builds the same BaProblem arrays, in the same order, as
+    prepare_cameras + prepare_observations + _to_arrays -- also on ragged input."""
+    from structure_from_motion_amd.session import BASession
+    g = load_golden("marshalling")
+    ids, image_data, pts = _image_data_from_golden(g)
+    sess = BASession()
+
+    def both(image_data, visited, pts):
+        cams = BA.prepare_cameras_from_image_data(image_data, visited)
+        obs = BA.prepare_observations_from_image_data(image_data, visited, pts)
+        cam_ids = list(cams.keys())
+        want = BA._to_arrays(cams, pts, obs, cam_ids, set())
+        got, got_ids, colours = sess.marshal(image_data, pts, visited)
+        assert got_ids == cam_ids
+        for k in ("cam_pose", "cam_intr", "points", "obs_cam", "obs_pt", "obs_xy"):
+            np.testing.assert_array_equal(getattr(got, k), getattr(want, k), err_msg=k)
+            assert getattr(got, k).dtype == getattr(want, k).dtype
+        np.testing.assert_array_equal(colours, np.array(pts)[:, 3:6])
+        return got
+
+    a = both(image_data, ids, pts)
+    assert len(a.obs_cam) == len(g["obs_pt"])
+    both(image_data, ids[:4], pts)                                    # a prefix, as the incremental driver calls it
+    both(image_data, ids, pts[:30])                                   # references beyond the point list are dropped
+    # ragged: unknown id, short tuple, a numpy integer and an out-of-range reference, more refs than keypoints
+    image_data[999] = (1, 2)
+    ref = list(image_data[ids[0]][3]); ref[0] = np.int64(3); ref[1] = 10 ** 6
+    image_data[ids[0]] = image_data[ids[0]][:3] + (ref,) + image_data[ids[0]][4:]
+    e = image_data[ids[1]]
+    image_data[ids[1]] = e[:3] + (list(e[3]) + [5, 6],) + e[4:]
+    both(image_data, ids + [999, 1234], pts)
+    assert sess._kp_xy[ids[2]][2].shape == (len(image_data[ids[2]][5]), 2)   # keypoints converted once, cached
+    # schedule / guards as inter_ba (:314, :325)
+    assert sess.inter_ba(image_data, pts, ids[:3], ba_interval=2, verbose=False) == (pts, image_data, False)
+    assert sess.inter_ba({}, pts, ids[:4], ba_interval=2, verbose=False)[2] is False
+
+
 def test_guards_and_schedule_without_gpu():
     cams = {i: {"R": np.eye(3), "t": np.zeros((3, 1)), "K": np.eye(3)} for i in range(2)}
     pts = [[0, 0, 1, 0, 0, 0]] * 20
