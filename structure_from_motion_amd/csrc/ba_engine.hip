@@ -924,7 +924,7 @@ int ba_analyze(const BaProblem *prob, BaAnalysis *out) {
     }
     memset(out, 0, sizeof *out);
     out->n_chunks = (int64_t)s.ck_obs.size() - 1;
-    out->n_pair_entries = (int64_t)s.pair_entries.size();
+    out->n_pair_entries = s.n_pair_real;
     out->nnz_blocks_upper = (int64_t)s.upper_keys.size();
     out->nnz_blocks_full = (int64_t)s.bsr_col.size();
     out->n_direct_pairs = s.n_direct_pairs;

@@ -93,7 +93,10 @@ template <bool STAMP>
 __global__ __launch_bounds__(CHUNK_OBS) void k_build(const BuildArgs A) {
     __shared__ __attribute__((aligned(16))) double sT[CHUNK_OBS * 18];   // T = W L^-T per observation (6x3)
     __shared__ __attribute__((aligned(16))) double sP[CHUNK_PTS * 9];    // per point: V(6) g_p(3), then L^-1(6) u(3)
-    __shared__ __attribute__((aligned(16))) double sX[CHUNK_PAIRS * 36]; // per local pair: -sum T_i T_j^T
+    // per local pair: -sum T_i T_j^T.  Tile stride 37 doubles = 74 banks = 10 (mod 64): the tiles that the lanes of
+    // one ds_add_f64 hit fall into distinct banks up to 32 tiles apart (stride 36 repeats every 8 tiles)
+    constexpr int SXS = 37;
+    __shared__ __attribute__((aligned(16))) double sX[CHUNK_PAIRS * SXS];
     __shared__ __attribute__((aligned(16))) double sC[CHUNK_CAMS * 33];  // per local camera: U(21) g_c(6) g_red part(6)
     __shared__ double sRed[4];
     __shared__ unsigned char sLp[CHUNK_OBS];                             // local point of each observation
@@ -128,17 +131,20 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build(const BuildArgs A) {
     if (tid < nobs) sCs[tid] = A.cs_obs[ob + tid];
     if (tid <= ncam) sCsStart[tid] = A.ck_cs[csb + tid];
     for (int i = tid; i < ncam * 33; i += CHUNK_OBS) sC[i] = 0.0;
-    for (int i = tid; i < ntile * 36; i += CHUNK_OBS) sX[i] = 0.0;
-    // the Schur phase's slice of pair entries: fetched now, used four barriers later
+    for (int i = tid; i < ntile * SXS; i += CHUNK_OBS) sX[i] = 0.0;
+    // the Schur phase's pair entries of this lane pair (two runs of PAIR_RUN, first round): fetched now, used
+    // four barriers later
     const long long peb = A.ck_pe[ck];
-    const int E = (int)(A.ck_pe[ck + 1] - peb);
-    const int K = (E + (CHUNK_OBS / 2 - 1)) / (CHUNK_OBS / 2);
+    const int rounds = (int)((A.ck_pe[ck + 1] - peb) / (CHUNK_OBS * PAIR_RUN));
     const int half = tid & 1;
-    const int e0 = (tid >> 1) * K;
-    const int e1 = (e0 + K < E) ? e0 + K : E;
-    unsigned ents[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) ents[i] = (e0 + i < e1) ? A.pair_entries[peb + e0 + i] : 0u;
+    unsigned ents[2 * PAIR_RUN];
+    {
+        const uint4 *ep = reinterpret_cast<const uint4 *>(A.pair_entries + peb) + (size_t)(tid >> 1) * 2;
+        const uint4 e0 = rounds > 0 ? ep[0] : make_uint4(PAIR_NULL, PAIR_NULL, PAIR_NULL, PAIR_NULL);
+        const uint4 e1 = rounds > 0 ? ep[1] : make_uint4(PAIR_NULL, PAIR_NULL, PAIR_NULL, PAIR_NULL);
+        ents[0] = e0.x; ents[1] = e0.y; ents[2] = e0.z; ents[3] = e0.w;
+        ents[4] = e1.x; ents[5] = e1.y; ents[6] = e1.z; ents[7] = e1.w;
+    }
     __syncthreads();
 
     BA_STAMP(1);
@@ -335,32 +341,14 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build(const BuildArgs A) {
     BA_STAMP(8);
 
     // ---- phase 3: Schur-complement blocks and reduced gradient ----------------------------------
-    // The chunk's (observation i, observation j, pair) entries are sorted by pair.  Lane t takes a
-    // contiguous slice of them and one half (3 of 6 rows) of the 6x6 block -T_i T_j^T; the running
-    // half block stays in registers while the pair does not change and is added to the LDS tile
-    // only at a pair boundary.  The self entries (i == j) also carry -T_i u_p of the reduced gradient.
+    // The chunk's (observation i, observation j, pair) entries come in runs of up to PAIR_RUN entries of one
+    // pair (ba_symbolic.cpp).  A lane pair takes two runs per round; each lane keeps one half (3 of 6 rows) of
+    // the run's block -sum T_i T_j^T in registers and adds it to the pair's LDS tile once per run -- at the
+    // same instruction for all lanes.  Self entries (i == j) also carry -T_i u_p of the reduced gradient.
     // LDS reads of entry k+1 are issued before the arithmetic of entry k.
     {
-        double acc[18], gacc[3];
-        int cur = -1, cur_lc = -1;
-        auto flush = [&]() {
-            if (cur < CHUNK_PAIRS) {
-                double *d = &sX[cur * 36 + half * 18];
-#pragma unroll
-                for (int k = 0; k < 18; ++k) atomicAdd(&d[k], acc[k]);
-            } else {
-                double *d = &A.S[(size_t)A.ck_pair_slot[qb + cur] * 36 + half * 18];
-#pragma unroll
-                for (int k = 0; k < 18; ++k) atomicAdd(&d[k], acc[k]);
-            }
-            if (cur_lc >= 0 && cur_lc < CHUNK_CAMS) {
-                double *d = &sC[cur_lc * 33 + 27 + half * 3];
-#pragma unroll
-                for (int r = 0; r < 3; ++r) atomicAdd(&d[r], gacc[r]);
-            }
-        };
         auto fetch = [&](unsigned ent, double *a9, double *b18, double *u3) {
-            const int oi = ent & 255u, oj = (ent >> 8) & 255u;
+            const int oi = ent & 255u, oj = (ent >> 8) & 255u;  // (a null entry reads observation 0: harmless)
             const double *ti = &sT[oi * 18 + half * 9], *tj = &sT[oj * 18], *uu = &sP[(int)sLp[oi] * 9 + 6];
 #pragma unroll
             for (int k = 0; k < 9; ++k) a9[k] = ti[k];
@@ -369,41 +357,64 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build(const BuildArgs A) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) u3[k] = uu[k];
         };
-        auto accumulate = [&](unsigned ent, const double *a9, const double *b18, const double *u3) {
-            const int oi = ent & 255u, oj = (ent >> 8) & 255u, lpi = (int)(ent >> 16);
-            if (lpi != cur) {
-                if (cur >= 0) flush();
-                cur = lpi;
-                cur_lc = -1;
+        for (int round = 0; round < rounds; ++round) {
+            if (round > 0) {
+                const uint4 *ep = reinterpret_cast<const uint4 *>(A.pair_entries + peb) +
+                                  ((size_t)round * (CHUNK_OBS / 2) + (tid >> 1)) * 2;
+                const uint4 e0 = ep[0], e1 = ep[1];
+                ents[0] = e0.x; ents[1] = e0.y; ents[2] = e0.z; ents[3] = e0.w;
+                ents[4] = e1.x; ents[5] = e1.y; ents[6] = e1.z; ents[7] = e1.w;
+            }
+            double ta[2][9], tb[2][18], tu[2][3];
+            fetch(ents[0], ta[0], tb[0], tu[0]);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                double acc[18], gacc[3];
 #pragma unroll
                 for (int k = 0; k < 18; ++k) acc[k] = 0.0;
 #pragma unroll
-                for (int r = 0; r < 3; ++r) gacc[r] = 0.0;
+                for (int k = 0; k < 3; ++k) gacc[k] = 0.0;
+                int self_lc = -1;
+#pragma unroll
+                for (int i = 0; i < PAIR_RUN; ++i) {
+                    const int e = r * PAIR_RUN + i;
+                    if (e + 1 < 2 * PAIR_RUN) fetch(ents[e + 1], ta[(e + 1) & 1], tb[(e + 1) & 1], tu[(e + 1) & 1]);
+                    const unsigned ent = ents[e];
+                    if (!(ent & PAIR_NULL)) {
+                        const double *a9 = ta[e & 1], *b18 = tb[e & 1], *u3 = tu[e & 1];
+#pragma unroll
+                        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                            for (int c = 0; c < 6; ++c)
+                                acc[rr * 6 + c] -= a9[rr * 3] * b18[c * 3] + a9[rr * 3 + 1] * b18[c * 3 + 1] + a9[rr * 3 + 2] * b18[c * 3 + 2];
+                        const int oi = ent & 255u, oj = (ent >> 8) & 255u;
+                        if (oi == oj) {
+                            self_lc = sLc[oi];
+#pragma unroll
+                            for (int rr = 0; rr < 3; ++rr) gacc[rr] -= a9[rr * 3] * u3[0] + a9[rr * 3 + 1] * u3[1] + a9[rr * 3 + 2] * u3[2];
+                        }
+                    }
+                }
+                const unsigned first = ents[r * PAIR_RUN];
+                if (!(first & PAIR_NULL)) {
+                    const int cur = (int)(first >> 16);
+                    if (cur < CHUNK_PAIRS) {
+                        double *d = &sX[cur * SXS + half * 18];
+#pragma unroll
+                        for (int k = 0; k < 18; ++k) atomicAdd(&d[k], acc[k]);
+                    } else {
+                        double *d = &A.S[(size_t)A.ck_pair_slot[qb + cur] * 36 + half * 18];
+#pragma unroll
+                        for (int k = 0; k < 18; ++k) atomicAdd(&d[k], acc[k]);
+                    }
+                    if (self_lc >= 0 && self_lc < CHUNK_CAMS) {
+                        double *d = &sC[self_lc * 33 + 27 + half * 3];
+#pragma unroll
+                        for (int rr = 0; rr < 3; ++rr) atomicAdd(&d[rr], gacc[rr]);
+                    }
+                }
             }
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int c = 0; c < 6; ++c)
-                    acc[r * 6 + c] -= a9[r * 3] * b18[c * 3] + a9[r * 3 + 1] * b18[c * 3 + 1] + a9[r * 3 + 2] * b18[c * 3 + 2];
-            if (oi == oj) {
-                cur_lc = sLc[oi];
-#pragma unroll
-                for (int r = 0; r < 3; ++r) gacc[r] -= a9[r * 3] * u3[0] + a9[r * 3 + 1] * u3[1] + a9[r * 3 + 2] * u3[2];
-            }
-        };
-        double ta[2][9], tb[2][18], tu[2][3];
-        fetch(ents[0], ta[0], tb[0], tu[0]);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (i < 7) fetch(ents[i + 1], ta[(i + 1) & 1], tb[(i + 1) & 1], tu[(i + 1) & 1]);
-            if (e0 + i < e1) accumulate(ents[i], ta[i & 1], tb[i & 1], tu[i & 1]);
         }
-        for (int e = e0 + 8; e < e1; ++e) {
-            const unsigned ent = A.pair_entries[peb + e];
-            fetch(ent, ta[0], tb[0], tu[0]);
-            accumulate(ent, ta[0], tb[0], tu[0]);
-        }
-        if (cur >= 0) flush();
     }
     __syncthreads();
 
@@ -419,7 +430,7 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build(const BuildArgs A) {
     }
     for (int i = tid; i < ntile * 36; i += CHUNK_OBS) {
         const int l = i / 36, k = i - l * 36;
-        atomicAdd(&A.S[(size_t)A.ck_pair_slot[qb + l] * 36 + k], sX[i]);
+        atomicAdd(&A.S[(size_t)A.ck_pair_slot[qb + l] * 36 + k], sX[l * SXS + k]);
     }
     BA_STAMP(10);
 }

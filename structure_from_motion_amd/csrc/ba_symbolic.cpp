@@ -107,10 +107,36 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
         s.ck_pt.push_back(next_pt);
         s.ck_cam.push_back((int32_t)s.ck_cam_list.size());
         s.ck_pair.push_back((int32_t)ck_pair_key.size());
-        // entries of a chunk sorted by local pair: a lane walks a contiguous slice and keeps the
-        // running block in registers while the pair does not change
-        std::stable_sort(s.pair_entries.begin() + s.ck_pe.back(), s.pair_entries.end(),
-                         [](uint32_t a, uint32_t b) { return (a >> 16) < (b >> 16); });
+        // Entries of a chunk, sorted by local pair, are cut into RUNS of at most PAIR_RUN entries of one pair.
+        // A lane pair of the build kernel takes two runs per round (8 entry words, null-padded) and adds each
+        // run's block to the pair tile once, at the same instruction for every lane (no divergent flushes).
+        // Consecutive runs (usually the same pair) go to different waves, so their tile updates do not
+        // collide inside one LDS instruction.
+        {
+            const size_t b0 = (size_t)s.ck_pe.back();
+            std::stable_sort(s.pair_entries.begin() + b0, s.pair_entries.end(),
+                             [](uint32_t a, uint32_t b) { return (a >> 16) < (b >> 16); });
+            std::vector<uint32_t> sorted(s.pair_entries.begin() + b0, s.pair_entries.end());
+            s.n_pair_real += (int64_t)sorted.size();
+            std::vector<uint32_t> runs;  // PAIR_RUN words per run
+            for (size_t i = 0; i < sorted.size();) {
+                size_t j = i;
+                while (j < sorted.size() && (sorted[j] >> 16) == (sorted[i] >> 16)) ++j;
+                for (size_t k = i; k < j; k += PAIR_RUN)
+                    for (size_t u = 0; u < (size_t)PAIR_RUN; ++u) runs.push_back(k + u < j ? sorted[k + u] : PAIR_NULL);
+                i = j;
+            }
+            const size_t n_runs = runs.size() / PAIR_RUN, per_round = CHUNK_OBS;  // 128 lane pairs x 2 runs
+            const size_t rounds = (n_runs + per_round - 1) / per_round;
+            s.pair_entries.resize(b0);
+            s.pair_entries.resize(b0 + rounds * per_round * PAIR_RUN, PAIR_NULL);
+            for (size_t k = 0; k < n_runs; ++k) {
+                const size_t round = k / per_round, kk = k % per_round, r = kk / (per_round / 2), q = kk % (per_round / 2);
+                const size_t lane_pair = (q % 4) * 32 + q / 4;
+                for (size_t u = 0; u < (size_t)PAIR_RUN; ++u)
+                    s.pair_entries[b0 + ((round * (per_round / 2) + lane_pair) * 2 + r) * PAIR_RUN + u] = runs[k * PAIR_RUN + u];
+            }
+        }
         s.ck_pe.push_back((int64_t)s.pair_entries.size());
         s.max_chunk_cams = std::max(s.max_chunk_cams, cur_cams);
         s.max_chunk_pairs = std::max(s.max_chunk_pairs, (int)pair_map.size());

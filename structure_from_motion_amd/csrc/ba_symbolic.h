@@ -19,6 +19,8 @@ constexpr int CHUNK_OBS = 256;   // observations per chunk = threads per workgro
 constexpr int CHUNK_PTS = 112;   // points per chunk (LDS slots)
 constexpr int CHUNK_CAMS = 32;   // cameras with an LDS tile per chunk
 constexpr int CHUNK_PAIRS = 88;  // camera pairs with an LDS tile per chunk
+constexpr int PAIR_RUN = 4;     // pair entries per run (see Symbolic::pair_entries)
+constexpr uint32_t PAIR_NULL = 0x80000000u;  // padding entry (bit 31; local pair ids stay below 2^15)
 
 struct Symbolic {
     int n_cams = 0, n_free = 0, n_points = 0, n_pts_obs = 0;
@@ -43,7 +45,9 @@ struct Symbolic {
     std::vector<int32_t> ck_pair_slot;  // upper-triangle block slot per local pair
     std::vector<int64_t> raw_keys;      // (i<<32 | j) per local pair, same order as ck_pair_slot
     std::vector<int64_t> ck_pe;      // [n_chunks+1] into pair_entries
-    std::vector<uint32_t> pair_entries; // oi | oj<<8 | local_pair<<16 (oi, oj: observation index inside the chunk)
+    std::vector<uint32_t> pair_entries; // oi | oj<<8 | local_pair<<16 (oi, oj: observation index inside the chunk), in runs
+                                        // of PAIR_RUN words, PAIR_NULL-padded; per chunk whole rounds of CHUNK_OBS runs
+    int64_t n_pair_real = 0;            // entries that are not padding
     // reduced camera system pattern
     std::vector<int64_t> upper_keys; // sorted unique (i<<32 | j), i <= j, free-camera indices
     std::vector<int32_t> diag_slot;  // [n_free]
