@@ -138,6 +138,7 @@ struct BaHandle {
     DevBuf<short> o_lcam;
     DevBuf<double> o_xy;
     DevBuf<long long> ck_pe;
+    DevBuf<int> ck_pgrp;
     DevBuf<unsigned> pair_entries;
     // reduced system: one contiguous buffer [S | U | gc | gred | sums(4)]
     DevBuf<double> red;
@@ -222,7 +223,7 @@ BuildArgs build_args(BaHandle *h) {
     A.o_cam = h->o_cam.p; A.o_pt = h->o_pt.p; A.o_lcam = h->o_lcam.p; A.o_xy = h->o_xy.p;
     A.cam_free = h->cam_free.p;
     A.ck_obs = h->ck_obs.p; A.ck_pt = h->ck_pt.p; A.ck_cam = h->ck_cam.p; A.ck_cam_list = h->ck_cam_list.p;
-    A.ck_pair = h->ck_pair.p; A.ck_pair_slot = h->ck_pair_slot.p; A.ck_pe = h->ck_pe.p;
+    A.ck_pair = h->ck_pair.p; A.ck_pair_slot = h->ck_pair_slot.p; A.ck_pe = h->ck_pe.p; A.ck_pgrp = h->ck_pgrp.p;
     A.pair_entries = h->pair_entries.p;
     A.S = h->S; A.U = h->U; A.gc = h->gc; A.gred = h->gred;
     A.pt_linv = h->pt_linv.p; A.pt_u = h->pt_u.p;
@@ -500,6 +501,7 @@ int create_impl(const BaProblem *prob, const BaOptions *opt, BaHandle *h) {
         HIPCHK(h->ck_pe.upload(pe, st));
     }
     HIPCHK(h->pair_entries.upload(s.pair_entries, st));
+    HIPCHK(h->ck_pgrp.upload(s.ck_pgrp, st));
     const int nf = s.n_free;
     HIPCHK(h->Minv.alloc((size_t)nf * 36));
     HIPCHK(h->cam_gmax.alloc((size_t)nf));

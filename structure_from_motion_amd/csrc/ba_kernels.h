@@ -47,6 +47,7 @@ struct BuildArgs {
     const int *ck_cs;               // per chunk (n_local_cams + 1) offsets into cs_obs, at ck_cam[ck] + ck
     const unsigned char *cs_obs;    // per chunk: its observations (chunk-local index) grouped by local camera
     const long long *ck_pe;
+    const int *ck_pgrp;             // per chunk (n_local_pairs + 1) group offsets, at ck_pair[ck] + ck
     const unsigned *pair_entries;
     double *S, *U, *gc, *gred;      // reduced-system accumulators (zeroed before the launch)
     double *pt_linv, *pt_u;         // [n_pts_obs*6], [n_pts_obs*3]
@@ -93,16 +94,13 @@ template <bool STAMP>
 __global__ __launch_bounds__(CHUNK_OBS) void k_build(const BuildArgs A) {
     __shared__ __attribute__((aligned(16))) double sT[CHUNK_OBS * 18];   // T = W L^-T per observation (6x3)
     __shared__ __attribute__((aligned(16))) double sP[CHUNK_PTS * 9];    // per point: V(6) g_p(3), then L^-1(6) u(3)
-    // per local pair: -sum T_i T_j^T.  Tile stride 37 doubles = 74 banks = 10 (mod 64): the tiles that the lanes of
-    // one ds_add_f64 hit fall into distinct banks up to 32 tiles apart (stride 36 repeats every 8 tiles)
-    constexpr int SXS = 37;
-    __shared__ __attribute__((aligned(16))) double sX[CHUNK_PAIRS * SXS];
     __shared__ __attribute__((aligned(16))) double sC[CHUNK_CAMS * 33];  // per local camera: U(21) g_c(6) g_red part(6)
     __shared__ double sRed[4];
     __shared__ unsigned char sLp[CHUNK_OBS];                             // local point of each observation
     __shared__ unsigned char sCs[CHUNK_OBS];                             // observations grouped by local camera
     __shared__ unsigned char sLc[CHUNK_OBS];                             // local camera of each observation
     __shared__ int sCsStart[CHUNK_CAMS + 1];
+    __shared__ int sPg[CHUNK_OBS / 2 + 2], sSlot[CHUNK_OBS / 2 + 1];    // group offsets / S block slots of the first pairs
     // (phase 1 stages sqrt(w) Jc (2x6) and sqrt(w) r (2) per observation in sT, which is idle until phase 2b)
 
     const int ck = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
@@ -110,7 +108,6 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build(const BuildArgs A) {
     const int pb = A.ck_pt[ck], npts = A.ck_pt[ck + 1] - pb;
     const int cb = A.ck_cam[ck], ncam = A.ck_cam[ck + 1] - cb;
     const int qb = A.ck_pair[ck], npair = A.ck_pair[ck + 1] - qb;
-    const int ntile = npair < CHUNK_PAIRS ? npair : CHUNK_PAIRS;
     const int csb = cb + ck;
     const double lam = A.state->lambda;
 
@@ -130,14 +127,15 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build(const BuildArgs A) {
     for (int i = tid; i < npts * 9; i += CHUNK_OBS) sP[i] = 0.0;
     if (tid < nobs) sCs[tid] = A.cs_obs[ob + tid];
     if (tid <= ncam) sCsStart[tid] = A.ck_cs[csb + tid];
+    if (tid <= npair && tid <= CHUNK_OBS / 2) sPg[tid] = A.ck_pgrp[qb + ck + tid];  // (pairs beyond hold no first-round group)
+    if (tid < npair && tid <= CHUNK_OBS / 2) sSlot[tid] = A.ck_pair_slot[qb + tid];
     for (int i = tid; i < ncam * 33; i += CHUNK_OBS) sC[i] = 0.0;
-    for (int i = tid; i < ntile * SXS; i += CHUNK_OBS) sX[i] = 0.0;
-    // the Schur phase's pair entries of this lane pair (two runs of PAIR_RUN, first round): fetched now, used
+    // the Schur phase's pair entries of this lane pair (one group of PAIR_RUN words, first round): fetched now, used
     // four barriers later
     const long long peb = A.ck_pe[ck];
-    const int rounds = (int)((A.ck_pe[ck + 1] - peb) / (CHUNK_OBS * PAIR_RUN));
+    const int rounds = (int)((A.ck_pe[ck + 1] - peb) / ((CHUNK_OBS / 2) * PAIR_RUN));
     const int half = tid & 1;
-    unsigned ents[2 * PAIR_RUN];
+    unsigned ents[PAIR_RUN];
     {
         const uint4 *ep = reinterpret_cast<const uint4 *>(A.pair_entries + peb) + (size_t)(tid >> 1) * 2;
         const uint4 e0 = rounds > 0 ? ep[0] : make_uint4(PAIR_NULL, PAIR_NULL, PAIR_NULL, PAIR_NULL);
@@ -341,14 +339,16 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build(const BuildArgs A) {
     BA_STAMP(8);
 
     // ---- phase 3: Schur-complement blocks and reduced gradient ----------------------------------
-    // The chunk's (observation i, observation j, pair) entries come in runs of up to PAIR_RUN entries of one
-    // pair (ba_symbolic.cpp).  A lane pair takes two runs per round; each lane keeps one half (3 of 6 rows) of
-    // the run's block -sum T_i T_j^T in registers and adds it to the pair's LDS tile once per run -- at the
-    // same instruction for all lanes.  Self entries (i == j) also carry -T_i u_p of the reduced gradient.
+    // The chunk's (observation i, observation j) entries come in groups of PAIR_RUN entries of ONE camera pair
+    // (ba_symbolic.cpp).  Lane pair g reduces group g: each lane keeps one half (3 of 6 rows) of the partial
+    // block -sum T_i T_j^T in registers.  No LDS atomics: once every lane is done with T, the partial blocks
+    // are parked in sT (exactly 36 doubles per lane pair) and phase 4 sums the groups of each pair.
+    // Self entries (i == j) also carry -T_i u_p of the reduced gradient (camera tile, LDS atomics: few).
     // LDS reads of entry k+1 are issued before the arithmetic of entry k.
     {
         auto fetch = [&](unsigned ent, double *a9, double *b18, double *u3) {
-            const int oi = ent & 255u, oj = (ent >> 8) & 255u;  // (a null entry reads observation 0: harmless)
+            if (ent == PAIR_NULL) ent = 0u;  // a null entry reads observation 0: harmless
+            const int oi = ent & 255u, oj = (ent >> 8) & 255u;
             const double *ti = &sT[oi * 18 + half * 9], *tj = &sT[oj * 18], *uu = &sP[(int)sLp[oi] * 9 + 6];
 #pragma unroll
             for (int k = 0; k < 9; ++k) a9[k] = ti[k];
@@ -357,7 +357,8 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build(const BuildArgs A) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) u3[k] = uu[k];
         };
-        for (int round = 0; round < rounds; ++round) {
+        double acc[18];
+        for (int round = 0; round < (rounds > 0 ? rounds : 1); ++round) {
             if (round > 0) {
                 const uint4 *ep = reinterpret_cast<const uint4 *>(A.pair_entries + peb) +
                                   ((size_t)round * (CHUNK_OBS / 2) + (tid >> 1)) * 2;
@@ -365,61 +366,58 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build(const BuildArgs A) {
                 ents[0] = e0.x; ents[1] = e0.y; ents[2] = e0.z; ents[3] = e0.w;
                 ents[4] = e1.x; ents[5] = e1.y; ents[6] = e1.z; ents[7] = e1.w;
             }
-            double ta[2][9], tb[2][18], tu[2][3];
+            double gacc[3], ta[2][9], tb[2][18], tu[2][3];
+            int self_lc = -1;
+#pragma unroll
+            for (int k = 0; k < 18; ++k) acc[k] = 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) gacc[k] = 0.0;
             fetch(ents[0], ta[0], tb[0], tu[0]);
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                double acc[18], gacc[3];
+            for (int e = 0; e < PAIR_RUN; ++e) {
+                if (e + 1 < PAIR_RUN) fetch(ents[e + 1], ta[(e + 1) & 1], tb[(e + 1) & 1], tu[(e + 1) & 1]);
+                const unsigned ent = ents[e];
+                if (ent != PAIR_NULL) {
+                    const double *a9 = ta[e & 1], *b18 = tb[e & 1], *u3 = tu[e & 1];
 #pragma unroll
-                for (int k = 0; k < 18; ++k) acc[k] = 0.0;
+                    for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
-                for (int k = 0; k < 3; ++k) gacc[k] = 0.0;
-                int self_lc = -1;
+                        for (int c = 0; c < 6; ++c)
+                            acc[rr * 6 + c] -= a9[rr * 3] * b18[c * 3] + a9[rr * 3 + 1] * b18[c * 3 + 1] + a9[rr * 3 + 2] * b18[c * 3 + 2];
+                    const int oi = ent & 255u, oj = (ent >> 8) & 255u;
+                    if (oi == oj) {
+                        self_lc = sLc[oi];
 #pragma unroll
-                for (int i = 0; i < PAIR_RUN; ++i) {
-                    const int e = r * PAIR_RUN + i;
-                    if (e + 1 < 2 * PAIR_RUN) fetch(ents[e + 1], ta[(e + 1) & 1], tb[(e + 1) & 1], tu[(e + 1) & 1]);
-                    const unsigned ent = ents[e];
-                    if (!(ent & PAIR_NULL)) {
-                        const double *a9 = ta[e & 1], *b18 = tb[e & 1], *u3 = tu[e & 1];
-#pragma unroll
-                        for (int rr = 0; rr < 3; ++rr)
-#pragma unroll
-                            for (int c = 0; c < 6; ++c)
-                                acc[rr * 6 + c] -= a9[rr * 3] * b18[c * 3] + a9[rr * 3 + 1] * b18[c * 3 + 1] + a9[rr * 3 + 2] * b18[c * 3 + 2];
-                        const int oi = ent & 255u, oj = (ent >> 8) & 255u;
-                        if (oi == oj) {
-                            self_lc = sLc[oi];
-#pragma unroll
-                            for (int rr = 0; rr < 3; ++rr) gacc[rr] -= a9[rr * 3] * u3[0] + a9[rr * 3 + 1] * u3[1] + a9[rr * 3 + 2] * u3[2];
-                        }
-                    }
-                }
-                const unsigned first = ents[r * PAIR_RUN];
-                if (!(first & PAIR_NULL)) {
-                    const int cur = (int)(first >> 16);
-                    if (cur < CHUNK_PAIRS) {
-                        double *d = &sX[cur * SXS + half * 18];
-#pragma unroll
-                        for (int k = 0; k < 18; ++k) atomicAdd(&d[k], acc[k]);
-                    } else {
-                        double *d = &A.S[(size_t)A.ck_pair_slot[qb + cur] * 36 + half * 18];
-#pragma unroll
-                        for (int k = 0; k < 18; ++k) atomicAdd(&d[k], acc[k]);
-                    }
-                    if (self_lc >= 0 && self_lc < CHUNK_CAMS) {
-                        double *d = &sC[self_lc * 33 + 27 + half * 3];
-#pragma unroll
-                        for (int rr = 0; rr < 3; ++rr) atomicAdd(&d[rr], gacc[rr]);
+                        for (int rr = 0; rr < 3; ++rr) gacc[rr] -= a9[rr * 3] * u3[0] + a9[rr * 3 + 1] * u3[1] + a9[rr * 3 + 2] * u3[2];
                     }
                 }
             }
+            if (self_lc >= 0 && self_lc < CHUNK_CAMS) {
+                double *d = &sC[self_lc * 33 + 27 + half * 3];
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr) atomicAdd(&d[rr], gacc[rr]);
+            }
+            if (round > 0 && ents[0] != PAIR_NULL) {
+                // groups beyond the first CHUNK_OBS / 2 (rare): straight to HBM
+                double *d = &A.S[(size_t)A.ck_pair_slot[qb + (int)(ents[0] >> 16)] * 36 + half * 18];
+#pragma unroll
+                for (int k = 0; k < 18; ++k) atomicAdd(&d[k], acc[k]);
+            }
+            if (round == 0) {
+                // the first round's partial block waits in registers until no lane needs T any more
+#pragma unroll
+                for (int k = 0; k < 18; ++k) W[k] = acc[k];  // (W is dead since phase 2b: reuse its registers)
+            }
         }
+        __syncthreads();  // every lane is done reading T
+        double *park = &sT[(tid >> 1) * 36 + half * 18];
+#pragma unroll
+        for (int k = 0; k < 18; ++k) park[k] = W[k];
     }
     __syncthreads();
 
     BA_STAMP(9);
-    // ---- phase 4: one flush of the LDS pair tile per chunk ---------------------------------------
+    // ---- phase 4: one flush per chunk (fp64 atomics to HBM) ------------------------------------------
     for (int i = tid; i < ncam * 33; i += CHUNK_OBS) {
         const int l = i / 33, k = i - l * 33;
         const size_t f = (size_t)A.ck_cam_list[cb + l];
@@ -428,9 +426,25 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build(const BuildArgs A) {
         else if (k < 27) atomicAdd(&A.gc[f * 6 + (k - 21)], v);
         else atomicAdd(&A.gred[f * 6 + (k - 27)], v);
     }
-    for (int i = tid; i < ntile * 36; i += CHUNK_OBS) {
-        const int l = i / 36, k = i - l * 36;
-        atomicAdd(&A.S[(size_t)A.ck_pair_slot[qb + l] * 36 + k], sX[l * SXS + k]);
+    {
+        // Schur blocks: element k of pair l = sum over the pair's groups of the parked partial blocks.  Only pairs
+        // with a group in the first round are parked; their offsets and block slots were staged in phase 0.
+        const int np1 = npair < CHUNK_OBS / 2 ? npair : CHUNK_OBS / 2;
+        for (int i = tid; i < np1 * 36; i += CHUNK_OBS) {
+            const int l = i / 36, k = i - l * 36;
+            const int g0 = sPg[l];
+            int g1 = sPg[l + 1];
+            if (g1 > CHUNK_OBS / 2) g1 = CHUNK_OBS / 2;  // later rounds went to HBM directly
+            double v = 0.0;
+            for (int g = g0; g < g1; g += 4) {  // four partial blocks per trip, loads issued together
+                double x[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x[u] = sT[(g + u < g1 ? g + u : g0) * 36 + k];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v += (g + u < g1) ? x[u] : 0.0;
+            }
+            if (g1 > g0) atomicAdd(&A.S[(size_t)sSlot[l] * 36 + k], v);
+        }
     }
     BA_STAMP(10);
 }

@@ -84,6 +84,8 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
     // --- greedy chunking -----------------------------------------------------------------
     std::vector<int32_t> cam_stamp(std::max(s.n_free, 1), -1), cam_slot(std::max(s.n_free, 1), 0);
     std::unordered_map<int64_t, int32_t> pair_map;
+    std::vector<int32_t> pair_cnt;  // entries per local pair of the open chunk
+    int cur_groups = 0;
     std::vector<int64_t> ck_pair_key;  // parallel to ck_pair_slot
     s.ck_obs.push_back(0);
     s.ck_pt.push_back(0);
@@ -107,40 +109,39 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
         s.ck_pt.push_back(next_pt);
         s.ck_cam.push_back((int32_t)s.ck_cam_list.size());
         s.ck_pair.push_back((int32_t)ck_pair_key.size());
-        // Entries of a chunk, sorted by local pair, are cut into RUNS of at most PAIR_RUN entries of one pair.
-        // A lane pair of the build kernel takes two runs per round (8 entry words, null-padded) and adds each
-        // run's block to the pair tile once, at the same instruction for every lane (no divergent flushes).
-        // Consecutive runs (usually the same pair) go to different waves, so their tile updates do not
-        // collide inside one LDS instruction.
+        // Entries of a chunk, sorted by local pair, are cut into GROUPS of PAIR_RUN entry words of ONE camera pair
+        // (null-padded).  Lane pair g of the build kernel reduces group g to one 6x6 partial block in registers; the
+        // partial blocks of a pair (groups ck_pgrp[l] .. ck_pgrp[l+1]) are summed when the chunk is flushed, so the
+        // Schur phase needs no LDS atomics and no LDS tile per pair.  Groups beyond the first CHUNK_OBS / 2 of a
+        // chunk (second "round": long tracks, many small pairs) go to HBM with atomics straight from registers.
         {
             const size_t b0 = (size_t)s.ck_pe.back();
             std::stable_sort(s.pair_entries.begin() + b0, s.pair_entries.end(),
                              [](uint32_t a, uint32_t b) { return (a >> 16) < (b >> 16); });
             std::vector<uint32_t> sorted(s.pair_entries.begin() + b0, s.pair_entries.end());
             s.n_pair_real += (int64_t)sorted.size();
-            std::vector<uint32_t> runs;  // PAIR_RUN words per run
+            s.pair_entries.resize(b0);
+            int32_t n_groups = 0;
             for (size_t i = 0; i < sorted.size();) {
                 size_t j = i;
                 while (j < sorted.size() && (sorted[j] >> 16) == (sorted[i] >> 16)) ++j;
-                for (size_t k = i; k < j; k += PAIR_RUN)
-                    for (size_t u = 0; u < (size_t)PAIR_RUN; ++u) runs.push_back(k + u < j ? sorted[k + u] : PAIR_NULL);
+                s.ck_pgrp.push_back(n_groups);
+                for (size_t k = i; k < j; k += PAIR_RUN, ++n_groups)
+                    for (size_t u = 0; u < (size_t)PAIR_RUN; ++u) s.pair_entries.push_back(k + u < j ? sorted[k + u] : PAIR_NULL);
                 i = j;
             }
-            const size_t n_runs = runs.size() / PAIR_RUN, per_round = CHUNK_OBS;  // 128 lane pairs x 2 runs
-            const size_t rounds = (n_runs + per_round - 1) / per_round;
-            s.pair_entries.resize(b0);
+            s.ck_pgrp.push_back(n_groups);
+            const size_t per_round = CHUNK_OBS / 2;
+            const size_t rounds = ((size_t)n_groups + per_round - 1) / per_round;
             s.pair_entries.resize(b0 + rounds * per_round * PAIR_RUN, PAIR_NULL);
-            for (size_t k = 0; k < n_runs; ++k) {
-                const size_t round = k / per_round, kk = k % per_round, r = kk / (per_round / 2), q = kk % (per_round / 2);
-                const size_t lane_pair = (q % 4) * 32 + q / 4;
-                for (size_t u = 0; u < (size_t)PAIR_RUN; ++u)
-                    s.pair_entries[b0 + ((round * (per_round / 2) + lane_pair) * 2 + r) * PAIR_RUN + u] = runs[k * PAIR_RUN + u];
-            }
+            if (rounds > 1) s.n_direct_pairs += n_groups - (int32_t)per_round;
         }
         s.ck_pe.push_back((int64_t)s.pair_entries.size());
         s.max_chunk_cams = std::max(s.max_chunk_cams, cur_cams);
         s.max_chunk_pairs = std::max(s.max_chunk_pairs, (int)pair_map.size());
         pair_map.clear();
+        pair_cnt.clear();
+        cur_groups = 0;
         ++chunk;
         cur_obs = cur_pts = cur_cams = 0;
         obs_base = next_obs;
@@ -163,10 +164,11 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
                 for (int c = a; c < L; ++c) {
                     if (fidx[c] < 0) continue;
                     int64_t key = ((int64_t)fidx[a] << 32) | (uint32_t)fidx[c];
-                    if (!pair_map.count(key)) ++newp;  // (duplicates inside the point over-count: harmless)
+                    auto it = pair_map.find(key);  // (duplicates inside the point over-count: harmless)
+                    if (it == pair_map.end() || pair_cnt[it->second] % PAIR_RUN == 0) ++newp;  // opens a new group
                 }
             }
-            if (cur_cams + newc > CHUNK_CAMS || (int)pair_map.size() + newp > CHUNK_PAIRS) cut = true;
+            if (cur_cams + newc > CHUNK_CAMS || cur_groups + newp > CHUNK_OBS / 2) cut = true;
         }
         if (cut && cur_pts > 0) close_chunk(i, b);
         for (int a = 0; a < L; ++a) {
@@ -205,11 +207,12 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
                     lp = it->second;
                 }
                 const uint32_t oi = (uint32_t)(b + a - obs_base), oj = (uint32_t)(b + c - obs_base);
+                if ((size_t)lp >= pair_cnt.size()) pair_cnt.resize(lp + 1, 0);
                 s.pair_entries.push_back(oi | (oj << 8) | ((uint32_t)lp << 16));
-                if (lp >= CHUNK_PAIRS) s.n_direct_pairs++;
+                if (pair_cnt[lp]++ % PAIR_RUN == 0) ++cur_groups;
                 if (c != a && fidx[c] == fidx[a]) {  // same camera observing the point twice
                     s.pair_entries.push_back(oj | (oi << 8) | ((uint32_t)lp << 16));
-                    if (lp >= CHUNK_PAIRS) s.n_direct_pairs++;
+                    if (pair_cnt[lp]++ % PAIR_RUN == 0) ++cur_groups;
                 }
             }
         }

@@ -18,9 +18,8 @@ namespace ba {
 constexpr int CHUNK_OBS = 256;   // observations per chunk = threads per workgroup
 constexpr int CHUNK_PTS = 112;   // points per chunk (LDS slots)
 constexpr int CHUNK_CAMS = 32;   // cameras with an LDS tile per chunk
-constexpr int CHUNK_PAIRS = 88;  // camera pairs with an LDS tile per chunk
-constexpr int PAIR_RUN = 4;     // pair entries per run (see Symbolic::pair_entries)
-constexpr uint32_t PAIR_NULL = 0x80000000u;  // padding entry (bit 31; local pair ids stay below 2^15)
+constexpr int PAIR_RUN = 8;      // pair entries per group = per lane pair of the build kernel (see Symbolic::pair_entries)
+constexpr uint32_t PAIR_NULL = 0xFFFFFFFFu;  // padding entry (local pair ids stay below 0xFFFF: at most 256 * 257 / 2 pairs)
 
 struct Symbolic {
     int n_cams = 0, n_free = 0, n_points = 0, n_pts_obs = 0;
@@ -45,8 +44,9 @@ struct Symbolic {
     std::vector<int32_t> ck_pair_slot;  // upper-triangle block slot per local pair
     std::vector<int64_t> raw_keys;      // (i<<32 | j) per local pair, same order as ck_pair_slot
     std::vector<int64_t> ck_pe;      // [n_chunks+1] into pair_entries
-    std::vector<uint32_t> pair_entries; // oi | oj<<8 | local_pair<<16 (oi, oj: observation index inside the chunk), in runs
-                                        // of PAIR_RUN words, PAIR_NULL-padded; per chunk whole rounds of CHUNK_OBS runs
+    std::vector<uint32_t> pair_entries; // oi | oj<<8 | local_pair<<16 (oi, oj: observation index inside the chunk), in groups
+                                        // of PAIR_RUN words of one pair, PAIR_NULL-padded; per chunk whole rounds of CHUNK_OBS/2 groups
+    std::vector<int32_t> ck_pgrp;       // per chunk (n_local_pairs + 1) group offsets, at ck_pair[ck] + ck
     int64_t n_pair_real = 0;            // entries that are not padding
     // reduced camera system pattern
     std::vector<int64_t> upper_keys; // sorted unique (i<<32 | j), i <= j, free-camera indices
