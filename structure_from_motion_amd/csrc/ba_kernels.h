@@ -112,10 +112,31 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build(const BuildArgs A) {
     const double lam = A.state->lambda;
 
     BA_STAMP(0);
-    // this lane's observation: every global load of phase 1 is issued here, unconditionally (clamped index), so
-    // that the two dependent round trips (index -> camera / point data) overlap the staging below
+    // All global loads of the chunk are issued here, unconditionally (clamped indices: a branch around a load makes
+    // the compiler drain every outstanding load at its use), oldest first in the order they are needed:
+    //   1. the small per-chunk lists that are staged in LDS before the first barrier, and the Schur phase's pair
+    //      entries of this lane pair (one group of PAIR_RUN words, first round; used four barriers later),
+    //   2. this lane's observation (camera / point index, pixel),
+    //   3. its camera block and point (dependent on 2; only phase 1, after the barrier, waits for them).
     const bool act = tid < nobs;
     const int oo = ob + (act ? tid : 0);
+    const unsigned char st_cs = A.cs_obs[oo];
+    const int st_start = A.ck_cs[csb + (tid <= ncam ? tid : 0)];
+    const bool has_pg = tid <= npair && tid <= CHUNK_OBS / 2, has_slot = tid < npair && tid <= CHUNK_OBS / 2;
+    const int st_pg = A.ck_pgrp[qb + ck + (has_pg ? tid : 0)];  // (pairs beyond CHUNK_OBS / 2 hold no first-round group)
+    const int st_slot = A.ck_pair_slot[has_slot ? qb + tid : 0];
+    const long long peb = A.ck_pe[ck];
+    const int rounds = (int)((A.ck_pe[ck + 1] - peb) / ((CHUNK_OBS / 2) * PAIR_RUN));
+    const int half = tid & 1;
+    unsigned ents[PAIR_RUN];
+    {
+        // (a chunk without pair entries reads the next chunk's first words, or the padding at the end of the array)
+        const uint4 *ep = reinterpret_cast<const uint4 *>(A.pair_entries + peb) + (size_t)(tid >> 1) * 2;
+        const uint4 e0 = ep[0], e1 = ep[1];
+        const bool any = rounds > 0;
+        ents[0] = any ? e0.x : PAIR_NULL; ents[1] = any ? e0.y : PAIR_NULL; ents[2] = any ? e0.z : PAIR_NULL; ents[3] = any ? e0.w : PAIR_NULL;
+        ents[4] = any ? e1.x : PAIR_NULL; ents[5] = any ? e1.y : PAIR_NULL; ents[6] = any ? e1.z : PAIR_NULL; ents[7] = any ? e1.w : PAIR_NULL;
+    }
     const int cam = A.o_cam[oo];
     const int p = A.o_pt[oo];
     const int lc_ld = A.o_lcam[oo];
@@ -125,24 +146,11 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build(const BuildArgs A) {
     const double X0 = A.points[3 * (size_t)p], X1 = A.points[3 * (size_t)p + 1], X2 = A.points[3 * (size_t)p + 2];
     const double floor_now = A.state->floor;
     for (int i = tid; i < npts * 9; i += CHUNK_OBS) sP[i] = 0.0;
-    if (tid < nobs) sCs[tid] = A.cs_obs[ob + tid];
-    if (tid <= ncam) sCsStart[tid] = A.ck_cs[csb + tid];
-    if (tid <= npair && tid <= CHUNK_OBS / 2) sPg[tid] = A.ck_pgrp[qb + ck + tid];  // (pairs beyond hold no first-round group)
-    if (tid < npair && tid <= CHUNK_OBS / 2) sSlot[tid] = A.ck_pair_slot[qb + tid];
     for (int i = tid; i < ncam * 33; i += CHUNK_OBS) sC[i] = 0.0;
-    // the Schur phase's pair entries of this lane pair (one group of PAIR_RUN words, first round): fetched now, used
-    // four barriers later
-    const long long peb = A.ck_pe[ck];
-    const int rounds = (int)((A.ck_pe[ck + 1] - peb) / ((CHUNK_OBS / 2) * PAIR_RUN));
-    const int half = tid & 1;
-    unsigned ents[PAIR_RUN];
-    {
-        const uint4 *ep = reinterpret_cast<const uint4 *>(A.pair_entries + peb) + (size_t)(tid >> 1) * 2;
-        const uint4 e0 = rounds > 0 ? ep[0] : make_uint4(PAIR_NULL, PAIR_NULL, PAIR_NULL, PAIR_NULL);
-        const uint4 e1 = rounds > 0 ? ep[1] : make_uint4(PAIR_NULL, PAIR_NULL, PAIR_NULL, PAIR_NULL);
-        ents[0] = e0.x; ents[1] = e0.y; ents[2] = e0.z; ents[3] = e0.w;
-        ents[4] = e1.x; ents[5] = e1.y; ents[6] = e1.z; ents[7] = e1.w;
-    }
+    if (act) sCs[tid] = st_cs;
+    if (tid <= ncam) sCsStart[tid] = st_start;
+    if (has_pg) sPg[tid] = st_pg;
+    if (has_slot) sSlot[tid] = st_slot;
     __syncthreads();
 
     BA_STAMP(1);

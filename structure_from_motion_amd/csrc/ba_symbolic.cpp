@@ -220,6 +220,8 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
         cur_pts += 1;
     }
     if (cur_pts > 0) close_chunk(s.n_pts_obs, pstart[s.n_pts_obs]);
+    // (the build kernel prefetches one round of entries unconditionally: readable padding behind the last chunk)
+    s.pair_entries.resize(s.pair_entries.size() + (size_t)(CHUNK_OBS / 2) * PAIR_RUN, PAIR_NULL);
     // slots are resolved by finalize_pattern (the pattern may be a union over ranks)
     s.ck_pair_slot.assign(ck_pair_key.size(), -1);
     s.raw_keys.swap(ck_pair_key);
