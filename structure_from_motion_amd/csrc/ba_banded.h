@@ -29,6 +29,27 @@
 
 namespace ba {
 
+// One elimination front.  A long chain is eliminated from BOTH ends at once (two workgroups): the top side runs over
+// cameras 0 .. m-1 in natural order, the bottom side over cameras N-1 .. m+B in reversed order; both stop in front
+// of the separator (cameras m .. m+B-1), add their Schur complements and right-hand sides into one dense 6B x 6B
+// system (k_band_middle solves it) and the two backward substitutions run outwards from the separator.
+struct BandSide {
+    double *Lb;       // band storage of this side's system, in this side's camera order
+    double *g;        // its right-hand side (the separator rows are zero on the bottom side: counted once)
+    double *ywork;
+    int N;            // block columns of this side's system (eliminated part + separator)
+    int n_elim;       // block columns to eliminate (== N: no separator, the whole system is factored)
+    int flip;         // 1: reversed camera order; camera of column j = cam0 - j, else cam0 + j
+    int cam0;
+};
+struct BandArgs {
+    BandSide side[2];
+    int B;
+    double *mid;      // separator system: (6B)^2 matrix (lower part), then its right-hand side (6B), then its solution (6B)
+    double *x;        // solution, camera order
+    int *info;        // 0, or 1 + a block column with a non-positive pivot (zeroed before the launches)
+};
+
 #ifdef BA_BAND_TIMING  // tools/band_bench.hip: cycle stamps of one block column, per wave
 __device__ long long g_band_t[16 * 8];
 #define BA_BAND_STAMP(k) do { if (j == BA_BAND_TIMING && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 16) g_band_t[(threadIdx.x >> 6) * 8 + (k)] = clock64(); } while (0)
@@ -56,17 +77,36 @@ inline int band_threads(int B) {
     return ((n + 63) / 64) * 64;
 }
 
-__global__ void k_band_assemble(int n_upper, const long long *__restrict__ keys, const double *__restrict__ S, int B,
-                                double *__restrict__ Lb) {
+// Upper blocks S(i, j), i <= j, of the reduced camera system -> band storage of the one or two sides.
+// m < 0: one side (Lb0).  Otherwise cameras [0, m + B) go to the top side and cameras [m, N) reversed to the bottom
+// side; blocks inside the separator [m, m + B) are stored on the top side only.
+__global__ void k_band_assemble(int n_upper, const long long *__restrict__ keys, const double *__restrict__ S, int B, int N,
+                                int m, double *__restrict__ Lb0, double *__restrict__ Lb1) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_upper * 36) return;
     const int k = e / 36, ab = e - k * 36, a = ab / 6, b = ab - a * 6;
     const int i = (int)(keys[k] >> 32), j = (int)(keys[k] & 0xffffffffLL);  // i <= j, upper block (i, j)
-    const int d = j - i;
-    // lower block (j, i)[a][b] = S(i, j)[b][a]; column i of the band, offset d
-    double v = S[(size_t)k * 36 + b * 6 + a];
-    if (d == 0) v = 0.5 * (v + S[(size_t)k * 36 + ab]);
-    Lb[((size_t)i * (B + 1) + d) * 36 + ab] = v;
+    const int d = j - i, P = B + 1;
+    const double vt = S[(size_t)k * 36 + b * 6 + a];  // transposed element
+    const double v0 = S[(size_t)k * 36 + ab];
+    if (m < 0 || j < m + B) {
+        // lower block (j, i)[a][b] = S(i, j)[b][a]; column i of the band, offset d
+        Lb0[((size_t)i * P + d) * 36 + ab] = d == 0 ? 0.5 * (vt + v0) : vt;
+    }
+    if (m >= 0 && i >= m && !(j < m + B)) {
+        // reversed order: cameras i' = N-1-i >= j' = N-1-j, lower block (i', j') = rows of camera i, columns of camera j
+        const int jr = N - 1 - j;
+        Lb1[((size_t)jr * P + d) * 36 + ab] = d == 0 ? 0.5 * (vt + v0) : v0;
+    }
+}
+
+// right-hand sides of the two sides (m >= 0): top = g[0 .. m+B), bottom = g reversed with zero separator rows
+__global__ void k_band_rhs(int N, int B, int m, const double *__restrict__ g, double *__restrict__ g0, double *__restrict__ g1) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N * 6) return;
+    const int c = e / 6, k = e - c * 6;
+    if (c < m + B) g0[e] = g[e];
+    if (c >= m) g1[(size_t)(N - 1 - c) * 6 + k] = (c < m + B) ? 0.0 : g[e];
 }
 
 __device__ __forceinline__ double band_rsqrt(double d) {
@@ -113,10 +153,14 @@ __device__ __forceinline__ void band_wave_sync() {
 //   phase 2  column j+1 for the next step: sA = sA2 - L(., j) L(j+1, j)^T (36 P threads, 6 FMAs each); the pairs of
 //            the slot that left the window are refilled from the block row that slides in; right-hand side; L -> HBM.
 // The register window holds the blocks (r, c), j+2 <= c <= r <= j+P+1; slot of a row = row mod P.
-__global__ __launch_bounds__(BA_BAND_THREADS) void k_band_cholesky_solve(int N, int B, double *__restrict__ Lb,
-                                                                         const double *__restrict__ g,
-                                                                         double *__restrict__ ywork,
-                                                                         int *__restrict__ info) {
+// With a separator (n_elim < N) the side stops after n_elim columns and adds what is left of its window -- the Schur
+// complement on the separator cameras -- and of its right-hand side to the dense separator system.
+__global__ __launch_bounds__(BA_BAND_THREADS) void k_band_cholesky_solve(const BandArgs args) {
+    const BandSide side = args.side[blockIdx.x];
+    const int N = side.N, B = args.B, n_elim = side.n_elim;
+    double *__restrict__ Lb = side.Lb;
+    const double *__restrict__ g = side.g;
+    double *__restrict__ ywork = side.ywork;
     constexpr int PM = BA_BAND_MAX + 1;
     __shared__ __attribute__((aligned(16))) double sA[PM * 36];       // sA[d] = A(j + d, j), the column being eliminated
     __shared__ __attribute__((aligned(16))) double sA2[2][PM * 36];   // [c & 1][d]: A(c + d, c) of the next column(s), one update short
@@ -336,22 +380,119 @@ __global__ __launch_bounds__(BA_BAND_THREADS) void k_band_cholesky_solve(int N, 
         __syncthreads();
         BA_BAND_STAMP(5);
     };
-    for (int j = 0; j < N; j += 2) {
+    for (int j = 0; j < n_elim; j += 2) {
         column_step(j, pa);
-        if (j + 1 < N) column_step(j + 1, pb);
+        if (j + 1 < n_elim) column_step(j + 1, pb);
     }
-    if (aux >= 0 && N > 0) copy_column(N - 1);
-    if (tid == 0) *info = sBad;
+    if (aux >= 0 && n_elim > 0) copy_column(n_elim - 1);
+    if (tid == 0 && sBad != 0) atomicMax(args.info, sBad);
+    if (n_elim < N) {
+        // separator: rows / columns je .. je+B-1.  Column je is in sA, column je+1 in sA2 (complete once the last
+        // eliminated column has been applied to the window), the rest in the registers of the window threads.
+        const int je = n_elim, nm = 6 * B;
+        double *mid = args.mid, *mid_rhs = args.mid + (size_t)nm * nm;
+        if (is_win && je > 0) window_update(je - 1);
+        __syncthreads();
+        auto emit = [&](int tr, int tc, int a, int b, double v) {  // block (je + tr, je + tc) of THIS side, tr >= tc
+            if (!side.flip) {
+                if (tr == tc && a < b) return;
+                atomicAdd(&mid[(size_t)(tr * 6 + a) * nm + tc * 6 + b], v);
+            } else {  // reversed side: its lower block (tr, tc) holds rows of camera B-1-tr, columns of camera B-1-tc
+                if (tr == tc && a > b) return;
+                atomicAdd(&mid[(size_t)((B - 1 - tc) * 6 + b) * nm + (B - 1 - tr) * 6 + a], v);
+            }
+        };
+        if (tid < B * 36) {
+            const int d = tid / 36, ab = tid - d * 36;
+            emit(d, 0, ab / 6, ab % 6, sA[tid]);
+        }
+        if (tid < (B - 1) * 36) {
+            const int d = tid / 36, ab = tid - d * 36;
+            emit(d + 1, 1, ab / 6, ab % 6, sA2[(je + 1) & 1][tid]);
+        }
+        if (is_win && je > 0) {
+            const int jm = (je + 1) % P;
+            int m1 = s1 - jm, m2 = s2 - jm;
+            if (m1 < 0) m1 += P;
+            if (m2 < 0) m2 += P;
+            m1 += 2; m2 += 2;  // offsets of the two rows from je - 1
+            if (m1 >= 3 && m1 <= B && m2 >= 3 && m2 <= B) {
+                const int dr = m1 > m2 ? m1 : m2, dc = m1 > m2 ? m2 : m1;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int b = 0; b < 6; ++b) emit(dr - 1, dc - 1, h3 + i, b, acc[i][b]);
+            }
+        }
+        if (tid < B * 6) {
+            const int t = tid / 6, k = tid - t * 6;
+            atomicAdd(&mid_rhs[(side.flip ? B - 1 - t : t) * 6 + k], sB[((je + t) % Pb) * 6 + k]);
+        }
+    }
+}
+
+// The separator system (n = 6 B <= 96 unknowns, dense, lower part given): Cholesky and both substitutions in one
+// workgroup; the solution goes to mid + n^2 + n and into x (cameras m .. m+B-1).
+__global__ __launch_bounds__(128) void k_band_middle(const BandArgs args, int m) {
+    constexpr int NM = 6 * BA_BAND_MAX;
+    __shared__ double sM[NM * (NM + 1) / 2];  // packed lower triangle
+    __shared__ double sV[NM];
+    __shared__ int sBad;
+    const int n = 6 * args.B, tid = threadIdx.x;
+    const double *mid = args.mid, *rhs = args.mid + (size_t)n * n;
+    if (*args.info != 0) return;
+    if (tid == 0) sBad = 0;
+    for (int e = tid; e < n * n; e += 128) {
+        const int r = e / n, c = e - r * n;
+        if (c <= r) sM[r * (r + 1) / 2 + c] = mid[e];
+    }
+    for (int e = tid; e < n; e += 128) sV[e] = rhs[e];
+    __syncthreads();
+    for (int c = 0; c < n; ++c) {
+        const double d = sM[c * (c + 1) / 2 + c];
+        if (!(d > 0.0)) { if (tid == 0) sBad = 1; }
+        const double il = band_rsqrt(d > 0.0 ? d : 1.0);
+        __syncthreads();
+        for (int r = c + 1 + tid; r < n; r += 128) sM[r * (r + 1) / 2 + c] *= il;
+        if (tid == 0) { sM[c * (c + 1) / 2 + c] = il; sV[c] *= il; }  // reciprocal diagonal; forward substitution fused
+        __syncthreads();
+        const double yc = sV[c];
+        for (int r = c + 1 + tid; r < n; r += 128) {
+            const double lrc = sM[r * (r + 1) / 2 + c];
+            for (int k = c + 1; k <= r; ++k) sM[r * (r + 1) / 2 + k] = fma(-lrc, sM[k * (k + 1) / 2 + c], sM[r * (r + 1) / 2 + k]);
+            sV[r] = fma(-lrc, yc, sV[r]);
+        }
+        __syncthreads();
+    }
+    for (int c = n - 1; c >= 0; --c) {  // backward substitution L^T x = y
+        if (tid == 0) sV[c] *= sM[c * (c + 1) / 2 + c];
+        __syncthreads();
+        const double xc = sV[c];
+        for (int r = tid; r < c; r += 128) sV[r] = fma(-sM[c * (c + 1) / 2 + r], xc, sV[r]);
+        __syncthreads();
+    }
+    if (sBad != 0) {
+        if (tid == 0) atomicMax(args.info, m + 1);
+        return;
+    }
+    double *xs = args.mid + (size_t)n * n + n;
+    for (int e = tid; e < n; e += 128) {
+        xs[e] = sV[e];
+        args.x[(size_t)m * 6 + e] = sV[e];
+    }
 }
 
 // Pre-scaling for the backward substitution (parallel over block columns, after the factorisation):
 //   Lb[j][d] <- W(j+d, j) = L(j+d, j) L_jj^{-1}  (d >= 1),   ywork[j] <- L_jj^{-T} y_j,
 // which turns the backward recurrence into  x_j = yhat_j - sum_d W(j+d, j)^T x_{j+d}  with no triangular solve
 // on its serial chain.  grid = N, block >= 6 B + 1 threads: thread (d, a) rescales one block row.
-__global__ void k_band_scale(int N, int B, double *__restrict__ Lb, double *__restrict__ ywork, const int *__restrict__ info) {
-    if (*info != 0) return;
-    const int j = blockIdx.x, t = threadIdx.x, P = B + 1;
-    if (t > B * 6) return;
+__global__ void k_band_scale(const BandArgs args) {
+    if (*args.info != 0) return;
+    const BandSide side = args.side[blockIdx.y];
+    const int j = blockIdx.x, t = threadIdx.x, B = args.B, P = B + 1;
+    if (t > B * 6 || j >= side.n_elim) return;
+    double *__restrict__ Lb = side.Lb;
+    double *__restrict__ ywork = side.ywork;
     double L[6][6], il[6], Li[6][6];  // Li = inverse of the lower Cholesky factor of the stored diagonal block
     band_chol6(&Lb[(size_t)j * P * 36], L, il);
 #pragma unroll
@@ -417,15 +558,33 @@ __device__ __forceinline__ double band_readlane(double v, int lane) {
 // of column j - 1 (pairs q' = g + 8 i spread over the 8 lanes of a group, reduced with DPP) are evaluated one
 // column ahead, off the chain, from the solution window in LDS.  The window is stored twice (slots s and s + P)
 // so that a lane's reads are base + constant offsets without wrap-around; columns are prefetched three ahead.
-__global__ __launch_bounds__(BA_BAND_BACK_THREADS) void k_band_backward(int N, int B, const double *__restrict__ Lb,
-                                                                        const double *__restrict__ ywork,
-                                                                        double *__restrict__ x, const int *__restrict__ info) {
+// With a separator the recurrence of a side starts below it (column n_elim - 1) from the separator's solution.
+__global__ __launch_bounds__(BA_BAND_BACK_THREADS) void k_band_backward(const BandArgs args) {
     constexpr int PM = BA_BAND_MAX + 1;
     __shared__ __attribute__((aligned(16))) double sX[2 * PM * 6 + 8 * BA_BAND_BK + 24];
-    if (*info != 0) return;
-    const int P = B + 1;
+    if (*args.info != 0) return;
+    const BandSide side = args.side[blockIdx.x];
+    const int N = side.N, B = args.B, P = B + 1, start = side.n_elim;
+    const double *__restrict__ Lb = side.Lb;
+    const double *__restrict__ ywork = side.ywork;
+    double *__restrict__ x = args.x;
+    const long long xdir = side.flip ? -6 : 6, xorg = (long long)side.cam0 * 6;  // x index of (column j, k) = xorg + j xdir + k
     const int lane = threadIdx.x, bk = lane >> 3, bg = lane & 7;
     for (int e = lane; e < 2 * PM * 6 + 8 * BA_BAND_BK + 24; e += 64) sX[e] = 0.0;
+    band_wave_sync();
+    double xs[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // x_{j+1}, wave-uniform
+    if (start < N) {
+        // separator rows start .. start+B-1 of this side = separator cameras in this side's order
+        const double *xsep = args.mid + (size_t)(6 * B) * (6 * B) + 6 * B;
+        for (int e = lane; e < B * 6; e += 64) {
+            const int t = e / 6, k = e - t * 6, sl = (start + t) % P;
+            const double v = xsep[(side.flip ? B - 1 - t : t) * 6 + k];
+            sX[sl * 6 + k] = v;
+            sX[(sl + P) * 6 + k] = v;
+        }
+#pragma unroll
+        for (int a = 0; a < 6; ++a) xs[a] = xsep[(side.flip ? B - 1 : 0) * 6 + a];
+    }
     double msk[BA_BAND_BK];
 #pragma unroll
     for (int i = 0; i < BA_BAND_BK; ++i) msk[i] = (bg + 8 * i < 6 * (B - 1)) ? 1.0 : 0.0;
@@ -442,26 +601,48 @@ __global__ __launch_bounds__(BA_BAND_BACK_THREADS) void k_band_backward(int N, i
         for (int i = 0; i < BA_BAND_BK; ++i) c.wq[i] = cq[i * 48];
         c.y = ywork[jc * 6 + kk];
     };
+    // window values for column jc: x_{jc+d}[a], d >= 2, i.e. flattened index (jc % P) * 6 + 12 + q'
+    auto window_read = [&](int jc, double (&xv)[BA_BAND_BK]) {
+        int jm = jc % P;
+        if (jm < 0) jm += P;
+        const double *xw = &sX[jm * 6 + 12 + bg];
+#pragma unroll
+        for (int i = 0; i < BA_BAND_BK; ++i) xv[i] = xw[8 * i];
+    };
+    // base_jc = yhat_jc - (d >= 2 terms), reduced over the 8 lanes of a group
+    auto window_base = [&](const Col &cm, const double (&xv)[BA_BAND_BK]) -> double {
+        double p0 = 0.0, p1 = 0.0, p2 = 0.0;
+#pragma unroll
+        for (int i = 0; i + 2 < BA_BAND_BK; i += 3) {
+            p0 = fma(cm.wq[i] * msk[i], xv[i], p0);
+            p1 = fma(cm.wq[i + 1] * msk[i + 1], xv[i + 1], p1);
+            p2 = fma(cm.wq[i + 2] * msk[i + 2], xv[i + 2], p2);
+        }
+        double p = (p0 + p1) + p2;
+        p += band_dpp<0xB1>(p);   // quad_perm [1,0,3,2]
+        p += band_dpp<0x4E>(p);   // quad_perm [2,3,0,1]
+        p += band_dpp<0x141>(p);  // row_half_mirror: the other quad of the 8-lane group
+        return cm.y - p;
+    };
     // Two banks of three columns: a bank is refilled right after its last use, three columns before its next
     // use.  (The compiler drains all outstanding loads at the loop head; with this order the youngest of them
     // is three columns old there.)
     Col x0, x1, x2, y0, y1, y2;
-    load_col(N - 1, x0);
-    load_col(N - 2, x1);
-    load_col(N - 3, x2);
-    double xs[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // x_{j+1}, wave-uniform
-    double base = x0.y;                              // base_j = yhat_j - (d >= 2 terms); column N - 1 has none
+    load_col(start - 1, x0);
+    load_col(start - 2, x1);
+    load_col(start - 3, x2);
     band_wave_sync();
+    double base;
+    {
+        double xv[BA_BAND_BK];
+        window_read(start - 1, xv);
+        base = window_base(x0, xv);
+    }
     // step(j): cj = column j (its d = 1 part), cm = column j - 1 (its d >= 2 part and yhat)
     auto back_step = [&](const int j, const Col &cj, const Col &cm) {
         const int js = j % P;
-        // window reads for column j - 1: x_{j-1+d}[a], d >= 2, i.e. flattened index ((j-1) % P) * 6 + 12 + q'
-        int jm = js - 1;
-        if (jm < 0) jm += P;
-        const double *xw = &sX[jm * 6 + 12 + bg];
         double xv[BA_BAND_BK];
-#pragma unroll
-        for (int i = 0; i < BA_BAND_BK; ++i) xv[i] = xw[8 * i];
+        window_read(j - 1, xv);
         // chain: x_j[k] = base_j[k] - sum_a W(j+1, j)[a][k] x_{j+1}[a]
         double s0 = base, s1 = 0.0;
 #pragma unroll
@@ -475,24 +656,12 @@ __global__ __launch_bounds__(BA_BAND_BACK_THREADS) void k_band_backward(int N, i
         if (bg == 0 && bk < 6) {
             sX[js * 6 + bk] = xk;
             sX[(js + P) * 6 + bk] = xk;
-            x[(size_t)j * 6 + bk] = xk;
+            x[xorg + (long long)j * xdir + bk] = xk;
         }
-        // off the chain: base_{j-1}
-        double p0 = 0.0, p1 = 0.0, p2 = 0.0;
-#pragma unroll
-        for (int i = 0; i + 2 < BA_BAND_BK; i += 3) {
-            p0 = fma(cm.wq[i] * msk[i], xv[i], p0);
-            p1 = fma(cm.wq[i + 1] * msk[i + 1], xv[i + 1], p1);
-            p2 = fma(cm.wq[i + 2] * msk[i + 2], xv[i + 2], p2);
-        }
-        double p = (p0 + p1) + p2;
-        p += band_dpp<0xB1>(p);   // quad_perm [1,0,3,2]
-        p += band_dpp<0x4E>(p);   // quad_perm [2,3,0,1]
-        p += band_dpp<0x141>(p);  // row_half_mirror: the other quad of the 8-lane group
-        base = cm.y - p;
+        base = window_base(cm, xv);  // off the chain: base_{j-1}
         band_wave_sync();
     };
-    for (int j = N - 1; j >= 0; j -= 6) {
+    for (int j = start - 1; j >= 0; j -= 6) {
         load_col(j - 3, y0);
         load_col(j - 4, y1);
         load_col(j - 5, y2);
@@ -507,6 +676,52 @@ __global__ __launch_bounds__(BA_BAND_BACK_THREADS) void k_band_backward(int N, i
         if (j >= 4) back_step(j - 4, y1, y2);
         if (j >= 5) back_step(j - 5, y2, x0);
     }
+}
+
+// ------------------------------------------------------------------------------------------ host side
+// Device buffers of one solve (owned by the caller).  sizes in doubles for N cameras, half bandwidth B:
+struct BandWork {
+    double *l, *y, *g, *mid;
+    int *info;
+};
+inline size_t band_l_doubles(int N, int B) { return ((size_t)N + B) * (B + 1) * 36 + 2 * BA_BAND_PAD; }
+inline size_t band_vec_doubles(int N, int B) { return ((size_t)N + B) * 6 + 16; }
+inline size_t band_mid_doubles(int B) { return (size_t)36 * B * B + 12 * B + 16; }
+// chains at least this long are eliminated from both ends
+inline bool band_two_sided(int N, int B) { return B >= 1 && N >= 6 * (B + 1); }
+
+// x = -S^{-1} g for the block-banded reduced camera system given by its upper blocks; *info (device) = 0 on success
+inline hipError_t band_solve_launch(hipStream_t st, int N, int B, int n_upper, const long long *keys, const double *S,
+                                    const double *g, double *x, const BandWork &w) {
+    const int P = B + 1;
+    hipError_t e;
+    if ((e = hipMemsetAsync(w.l, 0, band_l_doubles(N, B) * sizeof(double), st)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(w.info, 0, sizeof(int), st)) != hipSuccess) return e;
+    BandArgs a{};
+    a.B = B; a.mid = w.mid; a.x = x; a.info = w.info;
+    const bool two = band_two_sided(N, B);
+    const int m = two ? (N - B) / 2 : -1;
+    int sides = 1;
+    if (!two) {
+        a.side[0] = BandSide{w.l, const_cast<double *>(g), w.y, N, N, 0, 0};
+        a.side[1] = a.side[0];
+    } else {
+        sides = 2;
+        const int Nt = m + B, Nb = N - m;
+        a.side[0] = BandSide{w.l, w.g, w.y, Nt, m, 0, 0};
+        a.side[1] = BandSide{w.l + (size_t)Nt * P * 36 + BA_BAND_PAD, w.g + (size_t)Nt * 6, w.y + (size_t)Nt * 6, Nb, Nb - B, 1, N - 1};
+        if ((e = hipMemsetAsync(w.mid, 0, band_mid_doubles(B) * sizeof(double), st)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_band_rhs, dim3((N * 6 + 255) / 256), dim3(256), 0, st, N, B, m, g, a.side[0].g, a.side[1].g);
+    }
+    const int ne = n_upper * 36;
+    hipLaunchKernelGGL(k_band_assemble, dim3((ne + 255) / 256), dim3(256), 0, st, n_upper, keys, S, B, N, m, a.side[0].Lb,
+                       a.side[1].Lb);
+    hipLaunchKernelGGL(k_band_cholesky_solve, dim3(sides), dim3(band_threads(B)), 0, st, a);
+    if (two) hipLaunchKernelGGL(k_band_middle, dim3(1), dim3(128), 0, st, a, m);
+    const int ncol = two ? (a.side[0].n_elim > a.side[1].n_elim ? a.side[0].n_elim : a.side[1].n_elim) : N;
+    hipLaunchKernelGGL(k_band_scale, dim3(ncol, sides), dim3(((B * 6 + 1 + 63) / 64) * 64), 0, st, a);
+    hipLaunchKernelGGL(k_band_backward, dim3(sides), dim3(BA_BAND_BACK_THREADS), 0, st, a);
+    return hipGetLastError();
 }
 
 }  // namespace ba

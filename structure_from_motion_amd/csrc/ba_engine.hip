@@ -151,8 +151,7 @@ struct BaHandle {
     DevBuf<double> px, pr, pz, pp, pq, pqv;  // PCG: x, r, z, p (double-buffered: pp / pq), q = S p
     DevBuf<PcgScalars> pcg_sc;
     DevBuf<double> dense_a;          // dense reduced system (small camera counts only)
-    DevBuf<double> band_l, band_y;   // block-banded factor and forward-substitution work vector
-    bool band_attr_set = false;
+    DevBuf<double> band_l, band_y, band_g, band_mid;  // block-banded factor, work vectors, separator system
     DevBuf<long long> upper_keys;
     DevBuf<int> dense_info;
     int dense_fallbacks = 0;
@@ -346,26 +345,18 @@ int do_dense(BaHandle *h, bool *ok) {
 // block-banded Cholesky solve of S x = -g_red; *ok = false when S is not positive definite
 int do_banded(BaHandle *h, bool *ok) {
     hipStream_t st = h->stream;
-    const int N = h->sym.n_free, B = h->sym.band, P = B + 1;
+    const int N = h->sym.n_free, B = h->sym.band;
     *ok = true;
     if (N == 0) return BA_OK;
-    const size_t nb = (size_t)N * P * 36;
-    if (h->band_l.n != nb + BA_BAND_PAD) {
-        HIPCHK(h->band_l.alloc(nb + BA_BAND_PAD));
-        HIPCHK(h->band_y.alloc((size_t)N * 6));
+    if (h->band_l.n != band_l_doubles(N, B)) {
+        HIPCHK(h->band_l.alloc(band_l_doubles(N, B)));
+        HIPCHK(h->band_y.alloc(band_vec_doubles(N, B)));
+        HIPCHK(h->band_g.alloc(band_vec_doubles(N, B)));
+        HIPCHK(h->band_mid.alloc(band_mid_doubles(B)));
         if (h->dense_info.n == 0) HIPCHK(h->dense_info.alloc(1));
     }
-    HIPCHK(hipMemsetAsync(h->band_l.p, 0, (nb + BA_BAND_PAD) * sizeof(double), st));
-    const int ne = h->n_upper * 36;
-    hipLaunchKernelGGL(k_band_assemble, dim3((ne + 255) / 256), dim3(256), 0, st, h->n_upper, h->upper_keys.p, h->S, B,
-                       h->band_l.p);
-    hipLaunchKernelGGL(k_band_cholesky_solve, dim3(1), dim3(band_threads(B)), 0, st, N, B, h->band_l.p, h->gred, h->band_y.p,
-                       h->dense_info.p);
-    hipLaunchKernelGGL(k_band_scale, dim3(N), dim3(((B * 6 + 1 + 63) / 64) * 64), 0, st, N, B, h->band_l.p, h->band_y.p,
-                       h->dense_info.p);
-    hipLaunchKernelGGL(k_band_backward, dim3(1), dim3(BA_BAND_BACK_THREADS), 0, st, N, B, h->band_l.p, h->band_y.p, h->px.p,
-                       h->dense_info.p);
-    HIPCHK(hipGetLastError());
+    const BandWork w{h->band_l.p, h->band_y.p, h->band_g.p, h->band_mid.p, h->dense_info.p};
+    HIPCHK(band_solve_launch(st, N, B, h->n_upper, h->upper_keys.p, h->S, h->gred, h->px.p, w));
     int info = 0;
     HIPCHK(hipMemcpyAsync(&info, h->dense_info.p, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));

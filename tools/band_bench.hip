@@ -65,27 +65,39 @@ int main(int argc, char **argv) {
         for (int k = r + 1; k < n && k / 6 - r / 6 <= B; ++k) s -= Lr(k, r) * xr[k];
         xr[r] = s / Lr(r, r);
     }
-    double *dL0, *dL, *dg, *dx, *dy; int *dinfo;
-    CK(hipMalloc(&dL0, Lb.size() * 8)); CK(hipMalloc(&dL, (Lb.size() + BA_BAND_PAD) * 8)); CK(hipMemset(dL, 0, (Lb.size() + BA_BAND_PAD) * 8)); CK(hipMalloc(&dg, n * 8));
-    CK(hipMalloc(&dx, n * 8)); CK(hipMalloc(&dy, n * 8)); CK(hipMalloc(&dinfo, 4));
-    CK(hipMemcpy(dL0, Lb.data(), Lb.size() * 8, hipMemcpyHostToDevice));
+    // the solver's input format: upper blocks S(i, j), i <= j, keyed (i << 32 | j), row-major 6x6
+    std::vector<long long> keys;
+    std::vector<double> S;
+    for (int i = 0; i < N; ++i)
+        for (int j = i; j <= i + B && j < N; ++j) {
+            keys.push_back(((long long)i << 32) | (unsigned)j);
+            const double *low = &Lb[((size_t)i * P + (j - i)) * 36];  // lower block (j, i)
+            for (int a = 0; a < 6; ++a)
+                for (int b = 0; b < 6; ++b) S.push_back(low[b * 6 + a]);
+        }
+    const int n_upper = (int)keys.size();
+    long long *dkeys; double *dS, *dg, *dx; int *dinfo;
+    ba::BandWork w{};
+    CK(hipMalloc(&dkeys, keys.size() * 8)); CK(hipMalloc(&dS, S.size() * 8)); CK(hipMalloc(&dg, n * 8)); CK(hipMalloc(&dx, n * 8));
+    CK(hipMalloc(&w.l, ba::band_l_doubles(N, B) * 8)); CK(hipMalloc(&w.y, ba::band_vec_doubles(N, B) * 8));
+    CK(hipMalloc(&w.g, ba::band_vec_doubles(N, B) * 8)); CK(hipMalloc(&w.mid, ba::band_mid_doubles(B) * 8));
+    CK(hipMalloc(&dinfo, 4));
+    w.info = dinfo;
+    CK(hipMemcpy(dkeys, keys.data(), keys.size() * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dS, S.data(), S.size() * 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(dg, g.data(), n * 8, hipMemcpyHostToDevice));
-    hipEvent_t e0, e1, e2;
-    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
-    float tf = 0, tb = 0;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float tf = 0;
     for (int it = 0; it < reps + 1; ++it) {
-        CK(hipMemcpy(dL, dL0, Lb.size() * 8, hipMemcpyDeviceToDevice));
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(ba::k_band_cholesky_solve, dim3(1), dim3(ba::band_threads(B)), 0, 0, N, B, dL, dg, dy, dinfo);
+        CK(ba::band_solve_launch(0, N, B, n_upper, dkeys, dS, dg, dx, w));
         CK(hipEventRecord(e1));
-        hipLaunchKernelGGL(ba::k_band_scale, dim3(N), dim3(((B * 6 + 1 + 63) / 64) * 64), 0, 0, N, B, dL, dy, dinfo);
-        hipLaunchKernelGGL(ba::k_band_backward, dim3(1), dim3(BA_BAND_BACK_THREADS), 0, 0, N, B, dL, dy, dx, dinfo);
-        CK(hipEventRecord(e2));
         CK(hipDeviceSynchronize());
-        float a, b;
-        CK(hipEventElapsedTime(&a, e0, e1)); CK(hipEventElapsedTime(&b, e1, e2));
-        if (it > 0) { tf += a; tb += b; }
+        float a;
+        CK(hipEventElapsedTime(&a, e0, e1));
+        if (it > 0) tf += a;
     }
     std::vector<double> x(n);
     int info = -1;
@@ -93,8 +105,8 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(&info, dinfo, 4, hipMemcpyDeviceToHost));
     double err = 0, nrm = 0;
     for (int i = 0; i < n; ++i) { err = std::max(err, std::fabs(x[i] - xr[i])); nrm = std::max(nrm, std::fabs(xr[i])); }
-    printf("N=%d B=%d threads=%d info=%d  max|x-xref|=%.3e (|x|max %.3e)  forward %.3f ms (%.3f us/col)  backward %.3f ms (%.3f us/col)\n",
-           N, B, ba::band_threads(B), info, err, nrm, tf / reps, tf / reps / N * 1e3, tb / reps, tb / reps / N * 1e3);
+    printf("N=%d B=%d threads=%d two-sided=%d info=%d  max|x-xref|=%.3e (|x|max %.3e)  solve %.3f ms (%.3f us/col)\n",
+           N, B, ba::band_threads(B), (int)ba::band_two_sided(N, B), info, err, nrm, tf / reps, tf / reps / N * 1e3);
     long long ts[16 * 8];
     CK(hipMemcpyFromSymbol(ts, HIP_SYMBOL(ba::g_band_t), sizeof(ts)));
     printf("cycle stamps of column %d relative to wave 0 stamp 0 (A start, after chol6, A end, after barrier, B end, after barrier):\n", BA_BAND_TIMING);
