@@ -32,7 +32,8 @@ namespace ba {
 // One elimination front.  A long chain is eliminated from BOTH ends at once (two workgroups): the top side runs over
 // cameras 0 .. m-1 in natural order, the bottom side over cameras N-1 .. m+B in reversed order; both stop in front
 // of the separator (cameras m .. m+B-1), add their Schur complements and right-hand sides into one dense 6B x 6B
-// system (k_band_middle solves it) and the two backward substitutions run outwards from the separator.
+// system (itself a banded system of B cameras with half bandwidth B - 1: the same kernels solve it, one-sided) and
+// the two backward substitutions run outwards from the separator.
 struct BandSide {
     double *Lb;       // band storage of this side's system, in this side's camera order
     double *g;        // its right-hand side (the separator rows are zero on the bottom side: counted once)
@@ -45,7 +46,9 @@ struct BandSide {
 struct BandArgs {
     BandSide side[2];
     int B;
-    double *mid;      // separator system: (6B)^2 matrix (lower part), then its right-hand side (6B), then its solution (6B)
+    double *mid_l;    // separator system (B cameras, dense = band B - 1) in band storage, and
+    double *mid_g;    //   minus its right-hand side: solved by the same kernels as a one-sided system
+    int sep;          // first separator camera
     double *x;        // solution, camera order
     int *info;        // 0, or 1 + a block column with a non-positive pivot (zeroed before the launches)
 };
@@ -389,17 +392,16 @@ __global__ __launch_bounds__(BA_BAND_THREADS) void k_band_cholesky_solve(const B
     if (n_elim < N) {
         // separator: rows / columns je .. je+B-1.  Column je is in sA, column je+1 in sA2 (complete once the last
         // eliminated column has been applied to the window), the rest in the registers of the window threads.
-        const int je = n_elim, nm = 6 * B;
-        double *mid = args.mid, *mid_rhs = args.mid + (size_t)nm * nm;
+        const int je = n_elim;
+        double *mid = args.mid_l, *mid_g = args.mid_g;
         if (is_win && je > 0) window_update(je - 1);
         __syncthreads();
-        auto emit = [&](int tr, int tc, int a, int b, double v) {  // block (je + tr, je + tc) of THIS side, tr >= tc
+        // block (je + tr, je + tc) of THIS side, tr >= tc -> band storage of the separator system (column = lower camera)
+        auto emit = [&](int tr, int tc, int a, int b, double v) {
             if (!side.flip) {
-                if (tr == tc && a < b) return;
-                atomicAdd(&mid[(size_t)(tr * 6 + a) * nm + tc * 6 + b], v);
+                atomicAdd(&mid[((size_t)tc * B + (tr - tc)) * 36 + a * 6 + b], v);
             } else {  // reversed side: its lower block (tr, tc) holds rows of camera B-1-tr, columns of camera B-1-tc
-                if (tr == tc && a > b) return;
-                atomicAdd(&mid[(size_t)((B - 1 - tc) * 6 + b) * nm + (B - 1 - tr) * 6 + a], v);
+                atomicAdd(&mid[((size_t)(B - 1 - tr) * B + (tr - tc)) * 36 + b * 6 + a], v);
             }
         };
         if (tid < B * 36) {
@@ -424,61 +426,10 @@ __global__ __launch_bounds__(BA_BAND_THREADS) void k_band_cholesky_solve(const B
                     for (int b = 0; b < 6; ++b) emit(dr - 1, dc - 1, h3 + i, b, acc[i][b]);
             }
         }
-        if (tid < B * 6) {
+        if (tid < B * 6) {  // (the solver kernels take g and solve for -g: store minus the right-hand side)
             const int t = tid / 6, k = tid - t * 6;
-            atomicAdd(&mid_rhs[(side.flip ? B - 1 - t : t) * 6 + k], sB[((je + t) % Pb) * 6 + k]);
+            atomicAdd(&mid_g[(side.flip ? B - 1 - t : t) * 6 + k], -sB[((je + t) % Pb) * 6 + k]);
         }
-    }
-}
-
-// The separator system (n = 6 B <= 96 unknowns, dense, lower part given): Cholesky and both substitutions in one
-// workgroup; the solution goes to mid + n^2 + n and into x (cameras m .. m+B-1).
-__global__ __launch_bounds__(128) void k_band_middle(const BandArgs args, int m) {
-    constexpr int NM = 6 * BA_BAND_MAX;
-    __shared__ double sM[NM * (NM + 1) / 2];  // packed lower triangle
-    __shared__ double sV[NM];
-    __shared__ int sBad;
-    const int n = 6 * args.B, tid = threadIdx.x;
-    const double *mid = args.mid, *rhs = args.mid + (size_t)n * n;
-    if (*args.info != 0) return;
-    if (tid == 0) sBad = 0;
-    for (int e = tid; e < n * n; e += 128) {
-        const int r = e / n, c = e - r * n;
-        if (c <= r) sM[r * (r + 1) / 2 + c] = mid[e];
-    }
-    for (int e = tid; e < n; e += 128) sV[e] = rhs[e];
-    __syncthreads();
-    for (int c = 0; c < n; ++c) {
-        const double d = sM[c * (c + 1) / 2 + c];
-        if (!(d > 0.0)) { if (tid == 0) sBad = 1; }
-        const double il = band_rsqrt(d > 0.0 ? d : 1.0);
-        __syncthreads();
-        for (int r = c + 1 + tid; r < n; r += 128) sM[r * (r + 1) / 2 + c] *= il;
-        if (tid == 0) { sM[c * (c + 1) / 2 + c] = il; sV[c] *= il; }  // reciprocal diagonal; forward substitution fused
-        __syncthreads();
-        const double yc = sV[c];
-        for (int r = c + 1 + tid; r < n; r += 128) {
-            const double lrc = sM[r * (r + 1) / 2 + c];
-            for (int k = c + 1; k <= r; ++k) sM[r * (r + 1) / 2 + k] = fma(-lrc, sM[k * (k + 1) / 2 + c], sM[r * (r + 1) / 2 + k]);
-            sV[r] = fma(-lrc, yc, sV[r]);
-        }
-        __syncthreads();
-    }
-    for (int c = n - 1; c >= 0; --c) {  // backward substitution L^T x = y
-        if (tid == 0) sV[c] *= sM[c * (c + 1) / 2 + c];
-        __syncthreads();
-        const double xc = sV[c];
-        for (int r = tid; r < c; r += 128) sV[r] = fma(-sM[c * (c + 1) / 2 + r], xc, sV[r]);
-        __syncthreads();
-    }
-    if (sBad != 0) {
-        if (tid == 0) atomicMax(args.info, m + 1);
-        return;
-    }
-    double *xs = args.mid + (size_t)n * n + n;
-    for (int e = tid; e < n; e += 128) {
-        xs[e] = sV[e];
-        args.x[(size_t)m * 6 + e] = sV[e];
     }
 }
 
@@ -575,7 +526,7 @@ __global__ __launch_bounds__(BA_BAND_BACK_THREADS) void k_band_backward(const Ba
     double xs[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // x_{j+1}, wave-uniform
     if (start < N) {
         // separator rows start .. start+B-1 of this side = separator cameras in this side's order
-        const double *xsep = args.mid + (size_t)(6 * B) * (6 * B) + 6 * B;
+        const double *xsep = args.x + (size_t)args.sep * 6;  // solved before this launch
         for (int e = lane; e < B * 6; e += 64) {
             const int t = e / 6, k = e - t * 6, sl = (start + t) % P;
             const double v = xsep[(side.flip ? B - 1 - t : t) * 6 + k];
@@ -686,7 +637,9 @@ struct BandWork {
 };
 inline size_t band_l_doubles(int N, int B) { return ((size_t)N + B) * (B + 1) * 36 + 2 * BA_BAND_PAD; }
 inline size_t band_vec_doubles(int N, int B) { return ((size_t)N + B) * 6 + 16; }
-inline size_t band_mid_doubles(int B) { return (size_t)36 * B * B + 12 * B + 16; }
+inline size_t band_mid_doubles(int B) {  // separator system: band storage, right-hand side, work vector
+    return B < 1 ? 16 : band_l_doubles(B, B - 1) + 2 * band_vec_doubles(B, B - 1);
+}
 // chains at least this long are eliminated from both ends
 inline bool band_two_sided(int N, int B) { return B >= 1 && N >= 6 * (B + 1); }
 
@@ -698,7 +651,7 @@ inline hipError_t band_solve_launch(hipStream_t st, int N, int B, int n_upper, c
     if ((e = hipMemsetAsync(w.l, 0, band_l_doubles(N, B) * sizeof(double), st)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(w.info, 0, sizeof(int), st)) != hipSuccess) return e;
     BandArgs a{};
-    a.B = B; a.mid = w.mid; a.x = x; a.info = w.info;
+    a.B = B; a.x = x; a.info = w.info;
     const bool two = band_two_sided(N, B);
     const int m = two ? (N - B) / 2 : -1;
     int sides = 1;
@@ -710,6 +663,9 @@ inline hipError_t band_solve_launch(hipStream_t st, int N, int B, int n_upper, c
         const int Nt = m + B, Nb = N - m;
         a.side[0] = BandSide{w.l, w.g, w.y, Nt, m, 0, 0};
         a.side[1] = BandSide{w.l + (size_t)Nt * P * 36 + BA_BAND_PAD, w.g + (size_t)Nt * 6, w.y + (size_t)Nt * 6, Nb, Nb - B, 1, N - 1};
+        a.mid_l = w.mid;
+        a.mid_g = w.mid + band_l_doubles(B, B - 1);
+        a.sep = m;
         if ((e = hipMemsetAsync(w.mid, 0, band_mid_doubles(B) * sizeof(double), st)) != hipSuccess) return e;
         hipLaunchKernelGGL(k_band_rhs, dim3((N * 6 + 255) / 256), dim3(256), 0, st, N, B, m, g, a.side[0].g, a.side[1].g);
     }
@@ -717,7 +673,16 @@ inline hipError_t band_solve_launch(hipStream_t st, int N, int B, int n_upper, c
     hipLaunchKernelGGL(k_band_assemble, dim3((ne + 255) / 256), dim3(256), 0, st, n_upper, keys, S, B, N, m, a.side[0].Lb,
                        a.side[1].Lb);
     hipLaunchKernelGGL(k_band_cholesky_solve, dim3(sides), dim3(band_threads(B)), 0, st, a);
-    if (two) hipLaunchKernelGGL(k_band_middle, dim3(1), dim3(128), 0, st, a, m);
+    if (two) {
+        // the separator system: B cameras, half bandwidth B - 1, one-sided, solution straight into x
+        BandArgs c{};
+        c.B = B - 1; c.x = x; c.info = w.info;
+        c.side[0] = BandSide{a.mid_l, a.mid_g, a.mid_g + band_vec_doubles(B, B - 1), B, B, 0, m};
+        c.side[1] = c.side[0];
+        hipLaunchKernelGGL(k_band_cholesky_solve, dim3(1), dim3(band_threads(B - 1)), 0, st, c);
+        hipLaunchKernelGGL(k_band_scale, dim3(B, 1), dim3((((B - 1) * 6 + 1 + 63) / 64) * 64), 0, st, c);
+        hipLaunchKernelGGL(k_band_backward, dim3(1), dim3(BA_BAND_BACK_THREADS), 0, st, c);
+    }
     const int ncol = two ? (a.side[0].n_elim > a.side[1].n_elim ? a.side[0].n_elim : a.side[1].n_elim) : N;
     hipLaunchKernelGGL(k_band_scale, dim3(ncol, sides), dim3(((B * 6 + 1 + 63) / 64) * 64), 0, st, a);
     hipLaunchKernelGGL(k_band_backward, dim3(sides), dim3(BA_BAND_BACK_THREADS), 0, st, a);
