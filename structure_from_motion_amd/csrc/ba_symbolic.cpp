@@ -3,6 +3,9 @@
 #include "ba_symbolic.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <numeric>
 #include <unordered_map>
 
@@ -12,6 +15,9 @@ namespace ba {
 
 int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *cam_fixed,
                       const int32_t *obs_cam, const int32_t *obs_pt, Symbolic &s, const char **err) {
+    const bool tm_on = getenv("BA_TIME") != nullptr;
+    auto tm_t0 = std::chrono::steady_clock::now();
+    auto tick = [&](const char *what) { if (tm_on) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[symbolic] %-22s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(t - tm_t0).count()); tm_t0 = t; } };
     s = Symbolic();
     s.n_cams = n_cams;
     s.n_points = n_points;
@@ -31,6 +37,7 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
         }
         cnt[obs_pt[k]]++;
     }
+    tick("count");
     // --- point order: observed points sorted by (min camera, max camera), unobserved last ----
     std::vector<int32_t> cmin(n_points, INT32_MAX), cmax(n_points, -1);
     for (int64_t k = 0; k < n_obs; ++k) {
@@ -38,15 +45,27 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
         cmin[p] = std::min(cmin[p], c);
         cmax[p] = std::max(cmax[p], c);
     }
+    // (two stable counting passes, by max camera then by min camera: O(Np + Nc), keeps index order among ties)
     s.pt_order.resize(n_points);
-    std::iota(s.pt_order.begin(), s.pt_order.end(), 0);
-    std::stable_sort(s.pt_order.begin(), s.pt_order.end(), [&](int a, int b) {
-        bool ea = cnt[a] == 0, eb = cnt[b] == 0;
-        if (ea != eb) return eb;  // observed first
-        if (ea) return false;
-        if (cmin[a] != cmin[b]) return cmin[a] < cmin[b];
-        return cmax[a] < cmax[b];
-    });
+    {
+        std::vector<int32_t> tmp(n_points), head(n_cams + 2);
+        int n_obs_pts = 0;
+        for (int i = 0; i < n_points; ++i)
+            if (cnt[i] > 0) tmp[n_obs_pts++] = i;
+        int n_un = n_obs_pts;
+        for (int i = 0; i < n_points; ++i)
+            if (cnt[i] == 0) s.pt_order[n_un++] = i;  // unobserved points last, in index order
+        auto pass = [&](const std::vector<int32_t> &key, const int32_t *src, int32_t *dst) {
+            std::fill(head.begin(), head.end(), 0);
+            for (int i = 0; i < n_obs_pts; ++i) head[key[src[i]] + 1]++;
+            for (int c = 0; c <= n_cams; ++c) head[c + 1] += head[c];
+            for (int i = 0; i < n_obs_pts; ++i) dst[head[key[src[i]]]++] = src[i];
+        };
+        std::vector<int32_t> tmp2(n_obs_pts);
+        pass(cmax, tmp.data(), tmp2.data());
+        pass(cmin, tmp2.data(), s.pt_order.data());
+    }
+    tick("point sort");
     std::vector<int32_t> pt_inv(n_points);
     s.n_pts_obs = 0;
     for (int i = 0; i < n_points; ++i) {
@@ -64,6 +83,7 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
             std::sort(s.obs_order.begin() + pstart[i], s.obs_order.begin() + pstart[i + 1],
                       [&](int64_t a, int64_t b) { return obs_cam[a] != obs_cam[b] ? obs_cam[a] < obs_cam[b] : a < b; });
     }
+    tick("obs order");
     s.o_cam.resize(n_obs);
     s.o_pt.resize(n_obs);
     s.o_lcam.resize(n_obs);
@@ -81,11 +101,23 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
         *err = "a point has more than BA_MAX_TRACK observations";
         return BA_ERR_UNSUPPORTED;
     }
+    tick("obs gather");
     // --- greedy chunking -----------------------------------------------------------------
     std::vector<int32_t> cam_stamp(std::max(s.n_free, 1), -1), cam_slot(std::max(s.n_free, 1), 0);
+    // local pair ids of the open chunk: a (slot, slot) table for cameras with an LDS slot, a hash map for the rest
     std::unordered_map<int64_t, int32_t> pair_map;
+    std::vector<int32_t> pair_lut((size_t)CHUNK_CAMS * CHUNK_CAMS, -1), lut_touched;
     std::vector<int32_t> pair_cnt;  // entries per local pair of the open chunk
-    int cur_groups = 0;
+    std::vector<uint32_t> sorted;   // scratch of close_chunk
+    std::vector<int32_t> pair_off;
+    int cur_groups = 0, cur_pairs = 0;
+    auto find_pair = [&](int fa, int fc, int chunk_now) -> int32_t {
+        if (cam_stamp[fa] != chunk_now || cam_stamp[fc] != chunk_now) return -1;
+        const int sa = cam_slot[fa], sc = cam_slot[fc];
+        if (sa >= 0 && sc >= 0) return pair_lut[(size_t)sa * CHUNK_CAMS + sc];
+        auto it = pair_map.find(((int64_t)fa << 32) | (uint32_t)fc);
+        return it == pair_map.end() ? -1 : it->second;
+    };
     std::vector<int64_t> ck_pair_key;  // parallel to ck_pair_slot
     s.ck_obs.push_back(0);
     s.ck_pt.push_back(0);
@@ -95,6 +127,14 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
     int chunk = 0, cur_obs = 0, cur_pts = 0, cur_cams = 0;
     int64_t obs_base = 0;
     s.cs_obs.assign((size_t)n_obs, 0);
+    {
+        double est = 0;  // pair entries: sum of L (L + 1) / 2, plus the padding of the groups
+        for (int i = 0; i < s.n_pts_obs; ++i) {
+            const double L = (double)(pstart[i + 1] - pstart[i]);
+            est += 0.5 * L * (L + 1);
+        }
+        s.pair_entries.reserve((size_t)(est * 1.25) + 4096);
+    }
     std::vector<int32_t> cs_count;
     auto close_chunk = [&](int next_pt, int64_t next_obs) {
         // observations of the chunk grouped by local camera slot (counting sort)
@@ -115,16 +155,21 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
         // Schur phase needs no LDS atomics and no LDS tile per pair.  Groups beyond the first CHUNK_OBS / 2 of a
         // chunk (second "round": long tracks, many small pairs) go to HBM with atomics straight from registers.
         {
-            const size_t b0 = (size_t)s.ck_pe.back();
-            std::stable_sort(s.pair_entries.begin() + b0, s.pair_entries.end(),
-                             [](uint32_t a, uint32_t b) { return (a >> 16) < (b >> 16); });
-            std::vector<uint32_t> sorted(s.pair_entries.begin() + b0, s.pair_entries.end());
-            s.n_pair_real += (int64_t)sorted.size();
+            const size_t b0 = (size_t)s.ck_pe.back(), ne = s.pair_entries.size() - b0;
+            // counting sort by local pair (stable: entries of a pair stay in point order)
+            pair_off.assign(cur_pairs + 1, 0);
+            for (int l = 0; l < cur_pairs; ++l) pair_off[l + 1] = pair_off[l] + pair_cnt[l];
+            sorted.resize(ne);
+            for (size_t k = 0; k < ne; ++k) {
+                const uint32_t ent = s.pair_entries[b0 + k];
+                sorted[pair_off[ent >> 16]++] = ent;
+            }
+            s.n_pair_real += (int64_t)ne;
             s.pair_entries.resize(b0);
             int32_t n_groups = 0;
-            for (size_t i = 0; i < sorted.size();) {
-                size_t j = i;
-                while (j < sorted.size() && (sorted[j] >> 16) == (sorted[i] >> 16)) ++j;
+            size_t i = 0;
+            for (int l = 0; l < cur_pairs; ++l) {
+                const size_t j = i + pair_cnt[l];
                 s.ck_pgrp.push_back(n_groups);
                 for (size_t k = i; k < j; k += PAIR_RUN, ++n_groups)
                     for (size_t u = 0; u < (size_t)PAIR_RUN; ++u) s.pair_entries.push_back(k + u < j ? sorted[k + u] : PAIR_NULL);
@@ -138,10 +183,13 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
         }
         s.ck_pe.push_back((int64_t)s.pair_entries.size());
         s.max_chunk_cams = std::max(s.max_chunk_cams, cur_cams);
-        s.max_chunk_pairs = std::max(s.max_chunk_pairs, (int)pair_map.size());
+        s.max_chunk_pairs = std::max(s.max_chunk_pairs, cur_pairs);
         pair_map.clear();
+        for (int32_t t : lut_touched) pair_lut[t] = -1;
+        lut_touched.clear();
         pair_cnt.clear();
         cur_groups = 0;
+        cur_pairs = 0;
         ++chunk;
         cur_obs = cur_pts = cur_cams = 0;
         obs_base = next_obs;
@@ -163,9 +211,8 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
                 if (!seen) ++newc;
                 for (int c = a; c < L; ++c) {
                     if (fidx[c] < 0) continue;
-                    int64_t key = ((int64_t)fidx[a] << 32) | (uint32_t)fidx[c];
-                    auto it = pair_map.find(key);  // (duplicates inside the point over-count: harmless)
-                    if (it == pair_map.end() || pair_cnt[it->second] % PAIR_RUN == 0) ++newp;  // opens a new group
+                    const int32_t lp = find_pair(fidx[a], fidx[c], chunk);  // (duplicates inside the point over-count: harmless)
+                    if (lp < 0 || pair_cnt[lp] % PAIR_RUN == 0) ++newp;  // opens a new group
                 }
             }
             if (cur_cams + newc > CHUNK_CAMS || cur_groups + newp > CHUNK_OBS / 2) cut = true;
@@ -196,15 +243,18 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
             if (fidx[a] < 0) continue;
             for (int c = a; c < L; ++c) {
                 if (fidx[c] < 0) continue;
-                int64_t key = ((int64_t)fidx[a] << 32) | (uint32_t)fidx[c];
-                auto it = pair_map.find(key);
-                int32_t lp;
-                if (it == pair_map.end()) {
-                    lp = (int32_t)pair_map.size();
-                    pair_map.emplace(key, lp);
+                int32_t lp = find_pair(fidx[a], fidx[c], chunk);
+                if (lp < 0) {
+                    lp = cur_pairs++;
+                    const int64_t key = ((int64_t)fidx[a] << 32) | (uint32_t)fidx[c];
+                    const int sa = cam_slot[fidx[a]], sc = cam_slot[fidx[c]];
+                    if (sa >= 0 && sc >= 0) {
+                        pair_lut[(size_t)sa * CHUNK_CAMS + sc] = lp;
+                        lut_touched.push_back(sa * CHUNK_CAMS + sc);
+                    } else {
+                        pair_map.emplace(key, lp);
+                    }
                     ck_pair_key.push_back(key);
-                } else {
-                    lp = it->second;
                 }
                 const uint32_t oi = (uint32_t)(b + a - obs_base), oj = (uint32_t)(b + c - obs_base);
                 if ((size_t)lp >= pair_cnt.size()) pair_cnt.resize(lp + 1, 0);
@@ -220,6 +270,7 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
         cur_pts += 1;
     }
     if (cur_pts > 0) close_chunk(s.n_pts_obs, pstart[s.n_pts_obs]);
+    tick("chunking");
     // (the build kernel prefetches one round of entries unconditionally: readable padding behind the last chunk)
     s.pair_entries.resize(s.pair_entries.size() + (size_t)(CHUNK_OBS / 2) * PAIR_RUN, PAIR_NULL);
     // slots are resolved by finalize_pattern (the pattern may be a union over ranks)
