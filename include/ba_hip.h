@@ -164,6 +164,10 @@ int ba_get_cost(BaHandle *h, double *cost);
  * and g_p[n_points*3] of the last ba_build. */
 int ba_get_reduced_system(BaHandle *h, double *s, double *g_red, double *u, double *g_c, double *v,
                           double *g_p);
+/* The same reduced camera system as it is stored: upper 6x6 blocks (row-major), keys[k] = (i << 32) | j with
+ * i <= j free-camera indices.  keys == blocks == NULL only returns the count.  For problems whose dense S
+ * would not fit (full BAL sizes). */
+int ba_get_reduced_blocks(BaHandle *h, int64_t *keys, double *blocks, int64_t capacity, int64_t *n_blocks);
 int ba_synchronize(BaHandle *h);
 
 #ifdef __cplusplus

@@ -292,6 +292,30 @@ def reduced_system(nb, cam_fixed, obs_cam, obs_pt, lam):
     return S, gred, Vinv, Dc, Dp
 
 
+def reduced_matvec(nb, cam_fixed, obs_cam, obs_pt, lam, v):
+    """Matrix-free S v and g_red of the same reduced system (vectorised: usable at full BAL sizes, where the
+    dense S of :func:`reduced_system` would not fit): S v = (U + lam D_c) v - W (V + lam D_p)^-1 W^T v."""
+    cam_fixed = np.asarray(cam_fixed).astype(bool)
+    U, gc, V, gp, W = nb["U"], nb["gc"], nb["V"], nb["gp"], nb["W"]
+    free = np.flatnonzero(~cam_fixed)
+    vc = np.zeros((len(cam_fixed), 6)); vc[free] = np.asarray(v).reshape(-1, 6)
+    Dp = np.clip(np.einsum("nii->ni", V), D_MIN, D_MAX)
+    Vd = V + lam * np.einsum("ni,ij->nij", Dp, np.eye(3))
+    seen = np.zeros(len(V), dtype=bool); seen[obs_pt] = True
+    Vd[~seen] = np.eye(3)                                    # unobserved points: no contribution
+    Vinv = np.linalg.inv(Vd)
+    Dc = np.clip(np.einsum("nii->ni", U), D_MIN, D_MAX)
+    out = np.einsum("nij,nj->ni", U, vc) + lam * Dc * vc
+    fo = ~cam_fixed[obs_cam]                                 # observations of free cameras
+    t = np.zeros((len(V), 3)); np.add.at(t, obs_pt[fo], np.einsum("nij,ni->nj", W[fo], vc[obs_cam[fo]]))
+    t = np.einsum("nij,nj->ni", Vinv, t)
+    np.subtract.at(out, obs_cam[fo], np.einsum("nij,nj->ni", W[fo], t[obs_pt[fo]]))
+    gred = gc.copy()
+    u = np.einsum("nij,nj->ni", Vinv, gp)
+    np.subtract.at(gred, obs_cam[fo], np.einsum("nij,nj->ni", W[fo], u[obs_pt[fo]]))
+    return out[free].reshape(-1), gred[free].reshape(-1)
+
+
 def lm_step(nb, cam_fixed, obs_cam, obs_pt, lam):
     """One damped Gauss-Newton step by Schur elimination: (delta_c (Nc,6), delta_p (Np,3))."""
     cam_fixed = np.asarray(cam_fixed).astype(bool)

@@ -22,7 +22,7 @@ EXPORTED = [
     "ba_version", "ba_last_error", "ba_default_options", "ba_solve", "ba_eval_residuals", "ba_eval_cost",
     "ba_eval_jacobian_blocks", "ba_eval_reprojection_errors", "ba_analyze", "ba_create", "ba_destroy",
     "ba_get_pattern", "ba_set_pattern", "ba_set_collective", "ba_build", "ba_build_bench", "ba_run",
-    "ba_get_state", "ba_get_cost", "ba_get_reduced_system", "ba_synchronize",
+    "ba_get_state", "ba_get_cost", "ba_get_reduced_system", "ba_get_reduced_blocks", "ba_synchronize",
 ]
 
 
@@ -107,6 +107,7 @@ def load():
     lib.ba_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ba_get_cost.argtypes = [C.c_void_p, P(C.c_double)]
     lib.ba_get_reduced_system.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+    lib.ba_get_reduced_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, P(C.c_int64)]
     lib.ba_synchronize.argtypes = [C.c_void_p]
     for name in EXPORTED:
         if name not in ("ba_last_error", "ba_default_options", "ba_create", "ba_destroy"):
@@ -289,14 +290,34 @@ class Handle:
         self._cb = COLLECTIVE_FN(tramp)
         check(self._lib.ba_set_collective(self.h, self._cb, None, int(rank), int(world)))
 
-    def reduced_system(self, want_points=True):
+    def reduced_system(self, want_points=True, want_dense=True):
         nf = int((self.arr.cam_fixed == 0).sum())
         nc, npnt = self.arr.struct.n_cams, self.arr.struct.n_points
-        S = np.empty((6 * nf, 6 * nf)); g = np.empty(6 * nf)
+        S = np.empty((6 * nf, 6 * nf)) if want_dense else None
+        g = np.empty(6 * nf)
         U = np.empty((nc, 6, 6)); gc = np.empty((nc, 6))
         V = np.empty((npnt, 3, 3)) if want_points else None
         gp = np.empty((npnt, 3)) if want_points else None
-        check(self._lib.ba_get_reduced_system(self.h, S.ctypes.data, g.ctypes.data, U.ctypes.data, gc.ctypes.data,
+        check(self._lib.ba_get_reduced_system(self.h, S.ctypes.data if want_dense else None, g.ctypes.data,
+                                              U.ctypes.data, gc.ctypes.data,
                                               V.ctypes.data if want_points else None,
                                               gp.ctypes.data if want_points else None))
         return dict(S=S, gred=g, U=U, gc=gc, V=V, gp=gp)
+
+    def reduced_blocks(self):
+        """Upper 6x6 blocks of the reduced camera system as stored: (i, j, blocks (n, 6, 6)), i <= j."""
+        n = C.c_int64(0)
+        check(self._lib.ba_get_reduced_blocks(self.h, None, None, 0, C.byref(n)))
+        keys = np.empty(n.value, dtype=np.int64); blocks = np.empty((n.value, 6, 6))
+        check(self._lib.ba_get_reduced_blocks(self.h, keys.ctypes.data, blocks.ctypes.data, n.value, C.byref(n)))
+        return (keys >> 32).astype(np.int64), (keys & 0xffffffff).astype(np.int64), blocks
+
+    def schur_matvec(self, v):
+        """S v from the stored blocks (host-side product; parity probe for sizes where dense S does not fit)."""
+        i, j, blk = self.reduced_blocks()
+        x = np.asarray(v, dtype=np.float64).reshape(-1, 6)
+        out = np.zeros_like(x)
+        np.add.at(out, i, np.einsum("nab,nb->na", blk, x[j]))
+        off = i != j
+        np.add.at(out, j[off], np.einsum("nab,na->nb", blk[off], x[i[off]]))
+        return out.reshape(-1)

@@ -774,6 +774,20 @@ int ba_get_cost(BaHandle *h, double *cost) {
     return residual_sum(h, cost, &rs);
 }
 
+int ba_get_reduced_blocks(BaHandle *h, int64_t *keys, double *blocks, int64_t capacity, int64_t *n_blocks) {
+    if (!h || !n_blocks) return fail(BA_ERR_INVALID, "null argument");
+    (void)hipSetDevice(h->device);
+    if (!h->built) return fail(BA_ERR_INVALID, "ba_build has not run");
+    const Symbolic &s = h->sym;
+    *n_blocks = (int64_t)s.upper_keys.size();
+    if (!keys && !blocks) return BA_OK;
+    if (capacity < *n_blocks) return fail(BA_ERR_INVALID, "capacity %lld < %lld blocks", (long long)capacity, (long long)*n_blocks);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (keys) std::copy(s.upper_keys.begin(), s.upper_keys.end(), keys);
+    if (blocks && *n_blocks) HIPCHK(hipMemcpy(blocks, h->S, (size_t)*n_blocks * 36 * sizeof(double), hipMemcpyDeviceToHost));
+    return BA_OK;
+}
+
 int ba_get_reduced_system(BaHandle *h, double *s_out, double *g_red, double *u, double *g_c, double *v, double *g_p) {
     if (!h) return fail(BA_ERR_INVALID, "null handle");
     (void)hipSetDevice(h->device);

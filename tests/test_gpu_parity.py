@@ -288,3 +288,32 @@ def test_mid_size_properties(gpu):
     w = O.irls_weights(f1, 1.0, "huber").reshape(-1, 2)
     gp = np.zeros_like(pts); np.add.at(gp, p["obs_pt"], np.einsum("nki,nk->ni", jp * w[:, :, None], f1.reshape(-1, 2)))
     assert abs(np.abs(gp).max() - s["grad_inf"]) <= 1e-6 * max(s["grad_inf"], 1e-12) or np.abs(gp).max() <= s["grad_inf"]
+
+
+@pytest.mark.parametrize("name", ["ladybug1723", "venice1778"])
+def test_full_size_bal_shapes(gpu, name):
+    """BASELINE.json configs 3 and 4 at FULL size (680 k / 5 M observations): size-independent properties against
+    the vectorised oracle -- cost, per-camera and per-point normal-equation blocks, reduced gradient, and the
+    reduced camera system through a matrix-free product S v (the dense oracle S would not fit)."""
+    p = synthetic.make_config(name)
+    arr = _capi.Arrays.from_dict(p)
+    nb = O.normal_blocks(*oracle_args(p), p["obs_xy"], 1.0, "huber", floor=1.0)
+    assert abs(_capi.eval_cost(arr, "huber", 1.0) - nb["F"]) <= 1e-12 * nb["F"]
+    lam = 1e-4
+    free = p["cam_fixed"] == 0
+    v = np.random.default_rng(1).normal(size=6 * int(free.sum()))
+    Sv, gred = O.reduced_matvec(nb, p["cam_fixed"], p["obs_cam"], p["obs_pt"], lam, v)
+    with _capi.Handle(arr, loss="huber", f_scale=1.0) as h:
+        h.build(lam)
+        assert abs(h.cost() - nb["F"]) <= 1e-12 * nb["F"]
+        r = h.reduced_system(want_points=True, want_dense=False)
+        # (norm-wise; the largest blocks belong to points close to a camera, whose 1/z^2 factors amplify rounding)
+        assert rel(r["U"][free], nb["U"][free]) < 1e-10 and rel(r["gc"][free], nb["gc"][free]) < 1e-10
+        assert rel(r["V"], nb["V"]) < 1e-10 and rel(r["gp"], nb["gp"]) < 1e-10
+        assert rel(r["gred"], gred) < 1e-8
+        assert rel(h.schur_matvec(v), Sv) < 1e-8
+        s = h.run(3)                                      # three LM steps: the cost goes down, and is what the oracle says
+        cp, pts = h.state()
+    assert s["accepted"] >= 1 and s["final_cost"] < s["initial_cost"]
+    f1 = O.residuals(cp, p["cam_intr"], pts, p["obs_cam"], p["obs_pt"], p["obs_xy"])
+    assert abs(O.cost(f1, 1.0, "huber") - s["final_cost"]) <= 1e-10 * s["final_cost"]

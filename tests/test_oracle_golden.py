@@ -97,3 +97,14 @@ def test_temple_shaped_fixture_pins_oracle():
     fr = O.residuals(cr, p["cam_intr"], pr, p["obs_cam"], p["obs_pt"], p["obs_xy"])
     np.testing.assert_allclose(fr, g["ref_fun"], rtol=1e-8, atol=1e-9)
     assert abs(O.cost(fr, float(g["f_scale"]), "huber") - float(g["ref_cost"])) <= 1e-10 * float(g["ref_cost"])
+
+
+def test_matrix_free_schur_product_equals_dense():
+    g = load_golden("ring_unobserved")
+    p = problem_of(g)
+    nb = O.normal_blocks(p["cam_pose"], p["cam_intr"], p["points"], p["obs_cam"], p["obs_pt"], p["obs_xy"], 1.0, "huber")
+    S, gred, _, _, _ = O.reduced_system(nb, p["cam_fixed"], p["obs_cam"], p["obs_pt"], 1e-3)
+    v = np.random.default_rng(0).normal(size=S.shape[0])
+    Sv, g2 = O.reduced_matvec(nb, p["cam_fixed"], p["obs_cam"], p["obs_pt"], 1e-3, v)
+    np.testing.assert_allclose(Sv, S @ v, rtol=1e-10, atol=1e-10 * np.abs(S @ v).max())
+    np.testing.assert_allclose(g2, gred, rtol=1e-10, atol=1e-10 * np.abs(gred).max())
