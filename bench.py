@@ -25,6 +25,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+FP64_PEAK_TFLOPS = 78.6  # MI355X fp64 vector peak (same guide)
 
 
 def algorithmic_bytes(n_obs, n_pts, n_cams):
@@ -50,6 +51,32 @@ def cpu_baseline(prob, budget_obs):
                       f"(host has {os.cpu_count()} cores, the path is single-threaded Python)"}
 
 
+def other_configs(_capi, synthetic):
+    """BASELINE.json's other single-GPU configurations, reported beside the headline line (not bench lines of their
+    own): the Temple-ring-shaped final BA as one host-to-host ba_solve call, and the Ladybug-1723 shape resident."""
+    out = {}
+    p = synthetic.make_config("temple")
+    arr = _capi.Arrays.from_dict(p)
+    t0 = time.perf_counter()
+    s = _capi.solve(arr, loss="huber", f_scale=1.0, max_iter=300)
+    out["temple_final_ba"] = {"cameras": len(p["cam_pose"]), "points": len(p["points"]), "observations": len(p["obs_cam"]),
+                              "status": s["status"], "lm_steps": s["iterations"], "cost": [s["initial_cost"], s["final_cost"]],
+                              "solve_ms": s["t_solve_ms"], "setup_ms": s["t_setup_ms"],
+                              "wall_ms_host_to_host": (time.perf_counter() - t0) * 1e3}
+    p = synthetic.make_config("ladybug1723")
+    with _capi.Handle(_capi.Arrays.from_dict(p), loss="huber", f_scale=1.0, max_iter=300) as h:
+        h.build_bench(1e-4, warmup=0, reps=3)
+        ms_pass, ms_k = h.build_bench(1e-4, warmup=0, reps=20)
+        t0 = time.perf_counter()
+        s = h.run(10)
+        h.synchronize()
+        dt = time.perf_counter() - t0
+    out["ladybug1723"] = {"observations": len(p["obs_cam"]), "build_ms": ms_pass, "k_build_ms": ms_k,
+                          "observations_per_sec": len(p["obs_cam"]) / (ms_pass * 1e-3),
+                          "lm_iters_per_sec": max(s["iterations"], 1) / dt, "lm_pcg_iterations": s["pcg_iterations"]}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -60,6 +87,7 @@ def main():
     ap.add_argument("--lm-steps", type=int, default=10)
     ap.add_argument("--cpu-sample-obs", type=int, default=150000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -123,6 +151,13 @@ def main():
     roofline = {"bound": "hbm", "kernel": "k_build", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg, "kernel_ms": ms_kernel}
+    # the kernel sits near the ridge: the fp64 VALU ceiling next to the HBM one.  Algorithmic flops:
+    # 430 per observation (projection, analytic blocks, U/V/W/g) + 108 + 108 (L + 1) per observation for the explicit
+    # Schur complement at mean track length L + 50 per point (3x3 factor)
+    track = n_obs / max(n_pts, 1)
+    flops = n_obs * (430.0 + 108.0 + 108.0 * (track + 1.0)) + 50.0 * n_pts
+    roofline["fp64_valu"] = {"achieved": flops / (ms_kernel * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": flops / (ms_kernel * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, "algorithmic_flops_per_launch": flops}
 
     # full LM iterations (build + PCG + back-substitution + trial cost + device-side accept logic)
     barrier()
@@ -144,9 +179,11 @@ def main():
         "lm_cost": [summ["initial_cost"], summ["final_cost"]],
         "roofline": roofline,
     }
+    h.close()
+    if rank == 0 and world == 1 and not args.no_other_configs:
+        out["other_configs"] = other_configs(_capi, synthetic)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(prob, args.cpu_sample_obs)
-    h.close()
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
