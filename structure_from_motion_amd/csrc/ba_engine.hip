@@ -42,6 +42,8 @@ int fail(int code, const char *fmt, ...) {
         if (_e != hipSuccess) return fail(BA_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
 
+#define BA_MAX_WORLD 64  // ranks of one sharded solve
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
@@ -195,7 +197,7 @@ int upload_pattern(BaHandle *h) {
         HIPCHK(h->upper_keys.upload(keys, st));
     }
     const size_t nS = (size_t)h->n_upper * 36, nU = (size_t)nf * 21, ng = (size_t)nf * 6;
-    HIPCHK(h->red.alloc(nS + nU + 2 * ng + 4));
+    HIPCHK(h->red.alloc(nS + nU + 2 * ng + 4 + BA_MAX_WORLD));  // tail: one slot per rank (see do_build)
     h->S = h->red.p;
     h->U = h->S + nS;
     h->gc = h->U + nU;
@@ -252,7 +254,7 @@ int do_build(BaHandle *h, bool timed) {
     hipStream_t st = h->stream;
     const int nf = h->sym.n_free;
     const size_t nred = (size_t)h->n_upper * 36 + (size_t)nf * 33 + 4;
-    HIPCHK(hipMemsetAsync(h->red.p, 0, nred * sizeof(double), st));
+    HIPCHK(hipMemsetAsync(h->red.p, 0, (nred + BA_MAX_WORLD) * sizeof(double), st));
     if (timed) HIPCHK(hipEventRecord(h->ev0, st));
     if (h->n_chunks > 0) {
         BuildArgs A = build_args(h);
@@ -267,9 +269,12 @@ int do_build(BaHandle *h, bool timed) {
     hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, h->n_chunks, 1, h->ck_cost.p, h->sums);
     hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(256), 0, st, h->n_chunks, h->ck_gmax.p, h->gm2.p);
     if (h->world > 1) {
-        int e = call_coll(h, h->red.p, (int64_t)nred, BA_REDUCE_SUM);
+        // ONE collective per build: the maximum over ranks of the point-gradient norm rides in the sum buffer,
+        // each rank's value in its own slot of the tail (zero elsewhere), and is maximised locally afterwards
+        hipLaunchKernelGGL(k_copy_scalar, dim3(1), dim3(1), 0, st, h->gm2.p, h->red.p + nred + h->rank);
+        int e = call_coll(h, h->red.p, (int64_t)nred + h->world, BA_REDUCE_SUM);
         if (e) return e;
-        if ((e = call_coll(h, h->gm2.p, 1, BA_REDUCE_MAX))) return e;
+        hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(256), 0, st, h->world, h->red.p + nred, h->gm2.p);
     }
     if (nf > 0)
         hipLaunchKernelGGL(k_finalize, dim3((nf + 63) / 64), dim3(64), 0, st, nf, h->U, h->gc, h->gred, h->S, h->diag_slot.p,
@@ -657,6 +662,7 @@ int ba_set_collective(BaHandle *h, BaCollectiveFn fn, void *user, int32_t rank, 
     if (!h) return fail(BA_ERR_INVALID, "null handle");
     h->coll = fn;
     h->coll_user = user;
+    if (world > BA_MAX_WORLD || rank < 0 || (world >= 1 && rank >= world)) return fail(BA_ERR_INVALID, "rank %d of %d (at most %d ranks)", rank, world, BA_MAX_WORLD);
     h->rank = rank;
     h->world = world < 1 ? 1 : world;
     return BA_OK;

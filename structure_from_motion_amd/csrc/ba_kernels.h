@@ -823,6 +823,7 @@ __global__ void k_reduce_max(int n, const double *__restrict__ in, double *__res
 }
 
 __global__ void k_add_scalar(double *p, double v) { *p += v; }
+__global__ void k_copy_scalar(const double *src, double *dst) { *dst = *src; }
 
 // after a build: F and ||g||_inf into the state. sums[0] = F (already all-reduced), gm[0], gm[1] = point / camera maxima
 __global__ void k_state_after_build(LmState *st, const double *sums, const double *gm) {
