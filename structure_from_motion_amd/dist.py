@@ -5,8 +5,8 @@ that owns a disjoint set of points together with ALL their observations (cameras
 builds its partial reduced camera system without communication.  Per LM step the ranks then
 exchange:
 
-  1. one all-reduce (sum) of the contiguous buffer [S blocks | U | g_c | g_red | cost],
-     one all-reduce (max) of the point-gradient norm;
+  1. one all-reduce (sum) of the contiguous buffer [S blocks | U | g_c | g_red | cost | one slot per rank]
+     (the slots carry each rank's point-gradient norm; their maximum is taken locally);
   2. the replicated PCG solve (no communication), then a broadcast of rank 0's camera step so
      that every rank holds bit-identical cameras;
   3. one 4-double all-reduce of the step statistics (model reduction, trial cost, norms) so that
