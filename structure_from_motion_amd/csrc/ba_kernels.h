@@ -91,7 +91,7 @@ __device__ __forceinline__ double block_max256(double v, double *scratch) {
         if (STAMP && tid == 0) A.stamps[(size_t)ck * 12 + (i)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 template <bool STAMP>
-__global__ __launch_bounds__(CHUNK_OBS) void k_build(const BuildArgs A) {
+__global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_build(const BuildArgs A) {
     __shared__ __attribute__((aligned(16))) double sT[CHUNK_OBS * 18];   // T = W L^-T per observation (6x3)
     __shared__ __attribute__((aligned(16))) double sP[CHUNK_PTS * 9];    // per point: V(6) g_p(3), then L^-1(6) u(3)
     __shared__ __attribute__((aligned(16))) double sC[CHUNK_CAMS * 33];  // per local camera: U(21) g_c(6) g_red part(6)
@@ -374,19 +374,18 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build(const BuildArgs A) {
                 ents[0] = e0.x; ents[1] = e0.y; ents[2] = e0.z; ents[3] = e0.w;
                 ents[4] = e1.x; ents[5] = e1.y; ents[6] = e1.z; ents[7] = e1.w;
             }
-            double gacc[3], ta[2][9], tb[2][18], tu[2][3];
+            double gacc[3], ta[1][9], tb[1][18], tu[1][3];
             int self_lc = -1;
 #pragma unroll
             for (int k = 0; k < 18; ++k) acc[k] = 0.0;
 #pragma unroll
             for (int k = 0; k < 3; ++k) gacc[k] = 0.0;
-            fetch(ents[0], ta[0], tb[0], tu[0]);
 #pragma unroll
             for (int e = 0; e < PAIR_RUN; ++e) {
-                if (e + 1 < PAIR_RUN) fetch(ents[e + 1], ta[(e + 1) & 1], tb[(e + 1) & 1], tu[(e + 1) & 1]);
+                fetch(ents[e], ta[0], tb[0], tu[0]);
                 const unsigned ent = ents[e];
                 if (ent != PAIR_NULL) {
-                    const double *a9 = ta[e & 1], *b18 = tb[e & 1], *u3 = tu[e & 1];
+                    const double *a9 = ta[0], *b18 = tb[0], *u3 = tu[0];
 #pragma unroll
                     for (int rr = 0; rr < 3; ++rr)
 #pragma unroll

@@ -16,8 +16,8 @@
 namespace ba {
 
 constexpr int CHUNK_OBS = 256;   // observations per chunk = threads per workgroup
-constexpr int CHUNK_PTS = 112;   // points per chunk (LDS slots)
-constexpr int CHUNK_CAMS = 32;   // cameras with an LDS tile per chunk
+constexpr int CHUNK_PTS = 100;   // points per chunk (LDS slots)
+constexpr int CHUNK_CAMS = 28;   // cameras with an LDS tile per chunk
 constexpr int PAIR_RUN = 8;      // pair entries per group = per lane pair of the build kernel (see Symbolic::pair_entries)
 constexpr uint32_t PAIR_NULL = 0xFFFFFFFFu;  // padding entry (local pair ids stay below 0xFFFF: at most 256 * 257 / 2 pairs)
 
