@@ -155,6 +155,12 @@ int ba_build(BaHandle *h, double lambda);
  * launch of the dominant (fused linearise+Schur) kernel. */
 int ba_build_bench(BaHandle *h, double lambda, int32_t warmup, int32_t reps, double *ms_per_pass,
                    double *ms_fused_kernel);
+/* New values for the SAME structure (f1: device-resident problem reuse).  prob must have the sizes, cam_fixed and
+ * (obs_cam, obs_pt) of the problem the handle was created from (checked; BA_ERR_INVALID otherwise); cam_pose,
+ * cam_intr, points and obs_xy are uploaded again, opt (NULL = keep) replaces loss / tolerances / damping, and the
+ * LM state starts afresh.  Skips the symbolic analysis, every allocation and the index uploads of ba_create: what
+ * the reference's repeated inter_ba calls over an unchanged track set (sfm.py:184-191, 252-258) would re-pay. */
+int ba_set_values(BaHandle *h, const BaProblem *prob, const BaOptions *opt);
 /* Up to max_steps LM trial steps (continues from the current state); fills *out. */
 int ba_run(BaHandle *h, int32_t max_steps, BaSummary *out);
 int ba_get_state(BaHandle *h, double *cam_pose, double *points); /* host pointers, caller's order */

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libba_hip.so")
 
 BA_OK = 0
+BA_ERR_INVALID = -1
 LOSS = {"linear": 0, "soft_l1": 1, "huber": 2, "cauchy": 3, "arctan": 4}
 SOLVER = {"auto": 0, "pcg": 1, "dense_cholesky": 2, "banded_cholesky": 3}
 MEM_HOST, MEM_DEVICE = 0, 1
@@ -23,6 +24,7 @@ EXPORTED = [
     "ba_eval_jacobian_blocks", "ba_eval_reprojection_errors", "ba_analyze", "ba_create", "ba_destroy",
     "ba_get_pattern", "ba_set_pattern", "ba_set_collective", "ba_build", "ba_build_bench", "ba_run",
     "ba_get_state", "ba_get_cost", "ba_get_reduced_system", "ba_get_reduced_blocks", "ba_synchronize",
+    "ba_set_values",
 ]
 
 
@@ -109,6 +111,7 @@ def load():
     lib.ba_get_reduced_system.argtypes = [C.c_void_p] + [C.c_void_p] * 6
     lib.ba_get_reduced_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, P(C.c_int64)]
     lib.ba_synchronize.argtypes = [C.c_void_p]
+    lib.ba_set_values.argtypes = [C.c_void_p, P(BaProblem), P(BaOptions)]
     for name in EXPORTED:
         if name not in ("ba_last_error", "ba_default_options", "ba_create", "ba_destroy"):
             getattr(lib, name).restype = C.c_int
@@ -240,6 +243,14 @@ class Handle:
 
     def __exit__(self, *a):
         self.close()
+
+    def set_values(self, arr, **opts):
+        """New poses / intrinsics / points / observations for the SAME structure (``ba_set_values``): no symbolic
+        analysis, no allocation; the LM state starts afresh.  ``opts`` (if any) replace the handle's options."""
+        if opts:
+            self.opts = default_options(**opts)
+        check(self._lib.ba_set_values(self.h, C.byref(arr.struct), C.byref(self.opts) if opts else None))
+        self.arr = arr
 
     def build(self, lam=1e-4):
         check(self._lib.ba_build(self.h, float(lam)))

@@ -68,6 +68,12 @@ struct DevBuf {
         if (e != hipSuccess || v.empty()) return e;
         return hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
     }
+    // same as upload, but keeps the allocation when the size has not changed (ba_set_values)
+    hipError_t refill(const std::vector<T> &v, hipStream_t s) {
+        if (!p || n != v.size()) return upload(v, s);
+        if (v.empty()) return hipSuccess;
+        return hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
+    }
 };
 
 double now_ms() {
@@ -266,8 +272,7 @@ int do_build(BaHandle *h, bool timed) {
         }
     }
     if (timed) HIPCHK(hipEventRecord(h->ev1, st));
-    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, h->n_chunks, 1, h->ck_cost.p, h->sums);
-    hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(256), 0, st, h->n_chunks, h->ck_gmax.p, h->gm2.p);
+    hipLaunchKernelGGL(k_chunk_totals, dim3(1), dim3(1024), 0, st, h->n_chunks, h->ck_cost.p, h->ck_gmax.p, h->sums, h->gm2.p);
     if (h->world > 1) {
         // ONE collective per build: the maximum over ranks of the point-gradient norm rides in the sum buffer,
         // each rank's value in its own slot of the tail (zero elsewhere), and is maximised locally afterwards
@@ -279,8 +284,7 @@ int do_build(BaHandle *h, bool timed) {
     if (nf > 0)
         hipLaunchKernelGGL(k_finalize, dim3((nf + 63) / 64), dim3(64), 0, st, nf, h->U, h->gc, h->gred, h->S, h->diag_slot.p,
                            h->Minv.p, h->cam_gmax.p, h->state.p);
-    hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(256), 0, st, nf, h->cam_gmax.p, h->gm2.p + 1);
-    hipLaunchKernelGGL(k_state_after_build, dim3(1), dim3(1), 0, st, h->state.p, h->sums, h->gm2.p);
+    hipLaunchKernelGGL(k_state_after_build, dim3(1), dim3(256), 0, st, h->state.p, h->sums, h->gm2.p, nf, h->cam_gmax.p);
     HIPCHK(hipGetLastError());
     h->built = true;
     return BA_OK;
@@ -409,8 +413,8 @@ int do_step(BaHandle *h) {
         B.half_fs2 = 0.5 * h->opt.f_scale * h->opt.f_scale;
         hipLaunchKernelGGL(k_backsub, dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, B);
     }
-    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, h->n_chunks, 4, h->ck_part.p, h->step_sums.p);
-    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, s.n_cams, 2, h->cam_part.p, h->cam_sums.p);
+    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(1024), 0, st, h->n_chunks, 4, h->ck_part.p, h->step_sums.p);
+    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(1024), 0, st, s.n_cams, 2, h->cam_part.p, h->cam_sums.p);
     // |x|^2 of this rank's unobserved points joins the partial sums BEFORE the all-reduce so that
     // every rank takes the same decision
     hipLaunchKernelGGL(k_add_scalar, dim3(1), dim3(1), 0, st, h->step_sums.p + 3, h->x2_const);
@@ -431,6 +435,57 @@ int set_lambda(BaHandle *h, double lambda) {
     return BA_OK;
 }
 
+// The numeric half of a problem: values in the internal order, both state copies, camera constants, and a fresh
+// LM state.  The host vectors are read by asynchronous copies, hence the synchronise at the end.
+int upload_values(BaHandle *h, const HostProblem &hp) {
+    const Symbolic &s = h->sym;
+    hipStream_t st = h->stream;
+    std::vector<double> pts((size_t)s.n_points * 3), xy((size_t)s.n_obs * 2);
+    for (int i = 0; i < s.n_points; ++i)
+        for (int k = 0; k < 3; ++k) pts[3 * (size_t)i + k] = hp.points[3 * (size_t)s.pt_order[i] + k];
+    for (int64_t k = 0; k < s.n_obs; ++k) {
+        xy[2 * k] = hp.obs_xy[2 * s.obs_order[k]];
+        xy[2 * k + 1] = hp.obs_xy[2 * s.obs_order[k] + 1];
+    }
+    h->x2_const = 0.0;
+    for (int i = s.n_pts_obs; i < s.n_points; ++i)
+        for (int k = 0; k < 3; ++k) h->x2_const += pts[3 * (size_t)i + k] * pts[3 * (size_t)i + k];
+    for (int b = 0; b < 2; ++b) {
+        HIPCHK(h->pose[b].refill(hp.cam_pose, st));
+        HIPCHK(h->points[b].refill(pts, st));
+    }
+    HIPCHK(h->intr.refill(hp.cam_intr, st));
+    HIPCHK(h->o_xy.refill(xy, st));
+    LmState s0{};
+    s0.lambda = h->opt.lambda0;
+    s0.nu = 2.0;
+    s0.floor = 1.0;
+    s0.floor_min = h->opt.curv_floor;
+    h->hstate = s0;
+    h->cur = 0;
+    h->total_pcg = 0;
+    h->dense_fallbacks = 0;
+    h->initial_cost = NAN;
+    h->built = false;
+    HIPCHK(hipMemcpyAsync(h->state.p, &h->hstate, sizeof(LmState), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(h->gm2.p, 0, 2 * sizeof(double), st));
+    if (s.n_cams > 0)
+        hipLaunchKernelGGL(k_cam_prep, dim3((s.n_cams + 63) / 64), dim3(64), 0, st, s.n_cams, h->pose[0].p, h->intr.p,
+                           h->aux[0].p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    return BA_OK;
+}
+
+int check_options(BaOptions &o) {
+    if (!(o.f_scale > 0.0)) return fail(BA_ERR_INVALID, "f_scale must be positive");
+    if (o.loss < 0 || o.loss > 4) return fail(BA_ERR_INVALID, "unknown loss");
+    if (!(o.lambda0 > 0.0)) o.lambda0 = 1e-4;
+    if (!(o.pcg_tol > 0.0)) o.pcg_tol = 1e-8;
+    if (!(o.curv_floor > 0.0) || o.curv_floor > 1.0) o.curv_floor = 0.1;
+    return BA_OK;
+}
+
 int create_impl(const BaProblem *prob, const BaOptions *opt, BaHandle *h) {
     const double t0 = now_ms();
     int e = validate(prob);
@@ -438,11 +493,7 @@ int create_impl(const BaProblem *prob, const BaOptions *opt, BaHandle *h) {
     BaOptions o;
     if (opt) o = *opt;
     else ba_default_options(&o);
-    if (!(o.f_scale > 0.0)) return fail(BA_ERR_INVALID, "f_scale must be positive");
-    if (o.loss < 0 || o.loss > 4) return fail(BA_ERR_INVALID, "unknown loss");
-    if (!(o.lambda0 > 0.0)) o.lambda0 = 1e-4;
-    if (!(o.pcg_tol > 0.0)) o.pcg_tol = 1e-8;
-    if (!(o.curv_floor > 0.0) || o.curv_floor > 1.0) o.curv_floor = 0.1;
+    if ((e = check_options(o))) return e;
     h->opt = o;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(BA_ERR_HIP, "no HIP device available");
@@ -463,28 +514,11 @@ int create_impl(const BaProblem *prob, const BaOptions *opt, BaHandle *h) {
     Symbolic &s = h->sym;
     hipStream_t st = h->stream;
     h->n_chunks = (int)s.ck_obs.size() - 1;
-    // re-ordered copies
-    std::vector<double> pts((size_t)s.n_points * 3), xy((size_t)s.n_obs * 2);
-    for (int i = 0; i < s.n_points; ++i)
-        for (int k = 0; k < 3; ++k) pts[3 * (size_t)i + k] = hp.points[3 * (size_t)s.pt_order[i] + k];
-    for (int64_t k = 0; k < s.n_obs; ++k) {
-        xy[2 * k] = hp.obs_xy[2 * s.obs_order[k]];
-        xy[2 * k + 1] = hp.obs_xy[2 * s.obs_order[k] + 1];
-    }
-    h->x2_const = 0.0;
-    for (int i = s.n_pts_obs; i < s.n_points; ++i)
-        for (int k = 0; k < 3; ++k) h->x2_const += pts[3 * (size_t)i + k] * pts[3 * (size_t)i + k];
-    for (int b = 0; b < 2; ++b) {
-        HIPCHK(h->pose[b].upload(hp.cam_pose, st));
-        HIPCHK(h->points[b].upload(pts, st));
-        HIPCHK(h->aux[b].alloc((size_t)s.n_cams * BA_CAM_AUX));
-    }
-    HIPCHK(h->intr.upload(hp.cam_intr, st));
+    for (int b = 0; b < 2; ++b) HIPCHK(h->aux[b].alloc((size_t)s.n_cams * BA_CAM_AUX));
     HIPCHK(h->cam_free.upload(s.cam_free, st));
     HIPCHK(h->o_cam.upload(s.o_cam, st));
     HIPCHK(h->o_pt.upload(s.o_pt, st));
     HIPCHK(h->o_lcam.upload(s.o_lcam, st));
-    HIPCHK(h->o_xy.upload(xy, st));
     HIPCHK(h->ck_obs.upload(s.ck_obs, st));
     HIPCHK(h->ck_pt.upload(s.ck_pt, st));
     HIPCHK(h->ck_cam.upload(s.ck_cam, st));
@@ -518,19 +552,7 @@ int create_impl(const BaProblem *prob, const BaOptions *opt, BaHandle *h) {
     HIPCHK(h->pqv.alloc((size_t)nf * 6));
     HIPCHK(h->pcg_sc.alloc(1));
     HIPCHK(h->state.alloc(1));
-    LmState s0{};
-    s0.lambda = o.lambda0;
-    s0.nu = 2.0;
-    s0.floor = 1.0;
-    s0.floor_min = o.curv_floor;
-    h->hstate = s0;
-    HIPCHK(hipMemcpyAsync(h->state.p, &s0, sizeof s0, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemsetAsync(h->gm2.p, 0, 2 * sizeof(double), st));
-    if (s.n_cams > 0)
-        hipLaunchKernelGGL(k_cam_prep, dim3((s.n_cams + 63) / 64), dim3(64), 0, st, s.n_cams, h->pose[0].p, h->intr.p,
-                           h->aux[0].p);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(st));
+    if ((e = upload_values(h, hp))) return e;
     h->t_setup_ms = now_ms() - t0;
     return BA_OK;
 }
@@ -567,8 +589,8 @@ int residual_sum(BaHandle *h, double *cost, double *rsum) {
     hipLaunchKernelGGL(k_eval_cost, dim3(nb), dim3(256), 0, h->stream, n, h->aux[h->cur].p, h->points[h->cur].p, h->o_cam.p,
                        h->o_pt.p, h->o_xy.p, h->opt.loss, 1.0 / (h->opt.f_scale * h->opt.f_scale),
                        0.5 * h->opt.f_scale * h->opt.f_scale, bc.p, br.p);
-    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, h->stream, nb, 1, bc.p, out.p);
-    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, h->stream, nb, 1, br.p, out.p + 1);
+    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(1024), 0, h->stream, nb, 1, bc.p, out.p);
+    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(1024), 0, h->stream, nb, 1, br.p, out.p + 1);
     double host[2];
     HIPCHK(hipMemcpyAsync(host, out.p, sizeof host, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -626,6 +648,43 @@ void ba_destroy(BaHandle *h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     delete h;
+}
+
+int ba_set_values(BaHandle *h, const BaProblem *prob, const BaOptions *opt) {
+    if (!h) return fail(BA_ERR_INVALID, "null handle");
+    const double t0 = now_ms();
+    int e = validate(prob);
+    if (e) return e;
+    const Symbolic &s = h->sym;
+    if (prob->n_cams != s.n_cams || prob->n_points != s.n_points || prob->n_obs != s.n_obs)
+        return fail(BA_ERR_INVALID, "ba_set_values: sizes (%d cameras, %d points, %lld observations) differ from the handle's (%d, %d, %lld)",
+                    prob->n_cams, prob->n_points, (long long)prob->n_obs, s.n_cams, s.n_points, (long long)s.n_obs);
+    BaOptions o = h->opt;
+    if (opt) {
+        o = *opt;
+        o.device = h->opt.device;
+        if ((e = check_options(o))) return e;
+    }
+    (void)hipSetDevice(h->device);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HostProblem hp;
+    try {
+        if ((e = fetch_problem(prob, hp, false))) return e;
+        // the structure the handle was analysed for must be the caller's: same free set, same (camera, point) per observation
+        for (int c = 0; c < s.n_cams; ++c)
+            if ((hp.cam_fixed[c] != 0) != (s.cam_free[c] < 0)) return fail(BA_ERR_INVALID, "ba_set_values: cam_fixed[%d] changed", c);
+        for (int64_t k = 0; k < s.n_obs; ++k) {
+            const int64_t src = s.obs_order[k];
+            if (hp.obs_cam[src] != s.o_cam[k] || hp.obs_pt[src] != s.pt_order[s.o_pt[k]])
+                return fail(BA_ERR_INVALID, "ba_set_values: observation %lld names another (camera, point) than at ba_create", (long long)src);
+        }
+        h->opt = o;
+        if ((e = upload_values(h, hp))) return e;
+        h->t_setup_ms = now_ms() - t0;  // what this solve paid before its first build
+        return BA_OK;
+    } catch (const std::bad_alloc &) {
+        return fail(BA_ERR_NOMEM, "out of host memory");
+    }
 }
 
 int ba_get_pattern(BaHandle *h, int32_t *out_pairs, int64_t capacity, int64_t *n_pairs) {
@@ -1042,7 +1101,7 @@ int ba_eval_cost(const BaProblem *p, int32_t loss, double f_scale, double *out_c
     HIPCHK(o2.alloc(1));
     hipLaunchKernelGGL(k_eval_cost, dim3(nb), dim3(256), 0, 0, (long long)p->n_obs, c.aux.p, c.d_points, c.d_ocam, c.d_opt,
                        c.d_xy, loss, 1.0 / (f_scale * f_scale), 0.5 * f_scale * f_scale, bc.p, br.p);
-    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, 0, nb, 1, bc.p, o2.p);
+    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(1024), 0, 0, nb, 1, bc.p, o2.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(out_cost, o2.p, sizeof(double), hipMemcpyDeviceToHost));
     return BA_OK;

@@ -802,15 +802,36 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_backsub(const BacksubArgs A) {
 }
 
 // ------------------------------------------------------------------ deterministic reductions + LM control
-// out[k] = sum over i of in[i*stride + k] (k < stride), fixed order -> bitwise reproducible.
-__global__ void k_reduce_sum(int n, int stride, const double *__restrict__ in, double *__restrict__ out) {
-    __shared__ double red[4];
-    for (int k = 0; k < stride; ++k) {
-        double s = 0.0;
-        for (int i = threadIdx.x; i < n; i += 256) s += in[(size_t)i * stride + k];
-        s = block_sum256(s, red);
-        if (threadIdx.x == 0) out[k] = s;
-        __syncthreads();
+// out[k] = sum over i of in[i*stride + k] (k < stride <= 4), fixed order -> bitwise reproducible.  ONE block of 1024
+// threads; all loads of a trip (two rows, every column) are issued before any is used.
+__global__ __launch_bounds__(1024) void k_reduce_sum(int n, int stride, const double *__restrict__ in, double *__restrict__ out) {
+    __shared__ double red[16][4];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = threadIdx.x; i < n; i += 2048) {
+        const int i2 = i + 1024, j2 = i2 < n ? i2 : i;
+        double a[4], b[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int kk = k < stride ? k : 0;
+            a[k] = in[(size_t)i * stride + kk];
+            b[k] = in[(size_t)j2 * stride + kk];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            acc[k] += a[k];
+            acc[k] += i2 < n ? b[k] : 0.0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double v = wave_sum(acc[k]);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < stride) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += red[w][threadIdx.x];
+        out[threadIdx.x] = t;
     }
 }
 __global__ void k_reduce_max(int n, const double *__restrict__ in, double *__restrict__ out) {
@@ -824,10 +845,60 @@ __global__ void k_reduce_max(int n, const double *__restrict__ in, double *__res
 __global__ void k_add_scalar(double *p, double v) { *p += v; }
 __global__ void k_copy_scalar(const double *src, double *dst) { *dst = *src; }
 
-// after a build: F and ||g||_inf into the state. sums[0] = F (already all-reduced), gm[0], gm[1] = point / camera maxima
-__global__ void k_state_after_build(LmState *st, const double *sums, const double *gm) {
-    st->F = sums[0];
-    st->gmax = fmax(gm[0], gm[1]);
+// after k_build, ONE 1024-thread block: *sum_out = sum of the chunk costs (fixed order -> bitwise reproducible),
+// *max_out = max of the chunks' point-gradient maxima.  A one-block reduction is bound by load latency, so every
+// trip issues eight independent loads before it uses any.
+__global__ __launch_bounds__(1024) void k_chunk_totals(int n, const double *__restrict__ ck_cost, const double *__restrict__ ck_gmax,
+                                                       double *__restrict__ sum_out, double *__restrict__ max_out) {
+    __shared__ double rs[16], rm[16];
+    double s = 0.0, m = 0.0;
+    for (int i = threadIdx.x; i < n; i += 4096) {
+        double c[4], g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = i + u * 1024;
+            const int j = idx < n ? idx : i;
+            c[u] = ck_cost[j];
+            g[u] = ck_gmax[j];
+            if (idx >= n) c[u] = g[u] = 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            s += c[u];
+            m = fmax(m, g[u]);
+        }
+    }
+    s = wave_sum(s);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) {
+        rs[threadIdx.x >> 6] = s;
+        rm[threadIdx.x >> 6] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ts = 0.0, tm = 0.0;
+        for (int w = 0; w < 16; ++w) {
+            ts += rs[w];
+            tm = fmax(tm, rm[w]);
+        }
+        *sum_out = ts;
+        *max_out = tm;
+    }
+}
+
+// after a build (256 threads): F and ||g||_inf into the state.  sums[0] = F (already all-reduced), gm[0] = point
+// maximum (all-reduced), camera maximum = max of cam_gmax[0..nf) (replicated), kept in gm[1].
+__global__ __launch_bounds__(256) void k_state_after_build(LmState *st, const double *sums, double *gm, int nf,
+                                                           const double *__restrict__ cam_gmax) {
+    __shared__ double red[4];
+    double m = 0.0;
+    for (int i = threadIdx.x; i < nf; i += 256) m = fmax(m, cam_gmax[i]);
+    m = block_max256(m, red);
+    if (threadIdx.x == 0) {
+        gm[1] = m;
+        st->F = sums[0];
+        st->gmax = fmax(gm[0], m);
+    }
 }
 
 // after a trial step: gain ratio, accept / reject, damping update, termination (scipy _lsq/common.py:705-717)

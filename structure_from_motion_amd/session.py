@@ -8,8 +8,11 @@ coordinates of an image), and writes results back vectorised.  Semantics -- came
 order, validity rules, gauge, return values, in-place update of ``image_data`` -- are those of the module
 functions in ``BundleAdjustment.py`` of this package, which the tests compare it against.
 
-Not done yet: keeping the device buffers across calls.  The problem structure changes with every call
-of the incremental driver, so the host symbolic analysis reruns each time; only marshalling is saved.
+Device-resident reuse: the session keeps the engine handle of its last solve.  A call whose structure
+(camera set, gauge, (camera, point) of every observation) is the one the handle was analysed for goes through
+``ba_set_values`` -- values re-uploaded, no symbolic analysis, no allocation; any other call (the incremental
+driver's usual case: the track set grew) builds a new handle.  The C side compares the structures exactly, so a
+stale handle can never be used for another problem.  ``close()`` (or dropping the session) frees the handle.
 """
 import numpy as np
 
@@ -19,9 +22,48 @@ from .geometry import matrix_to_rvec, rvec_to_matrix
 
 
 class BASession:
-    def __init__(self):
+    def __init__(self, reuse_device=True):
         self._kp_xy = {}          # img_id -> (id of the keypoint list, its length, (k, 2) float64 coordinates)
         self.last_summary = None
+        self.reuse_device = reuse_device
+        self._handle = None       # engine handle of the last solve (structure + device buffers)
+        self.handle_reuses = 0
+
+    def close(self):
+        if self._handle is not None:
+            self._handle.close()
+            self._handle = None
+
+    def _run(self, arr, **opts):
+        """ba_solve's sequence (create | set_values, run, get_state) on the session's handle; arr is updated in place."""
+        h = self._handle
+        if h is not None:
+            same = (h.arr.struct.n_cams, h.arr.struct.n_points, h.arr.struct.n_obs) == \
+                   (arr.struct.n_cams, arr.struct.n_points, arr.struct.n_obs)
+            if same:
+                try:
+                    h.set_values(arr, **opts)
+                    self.handle_reuses += 1
+                except _capi.BaError as e:
+                    if e.code != _capi.BA_ERR_INVALID:
+                        raise
+                    same = False
+            if not same:
+                self.close()
+        if self._handle is None:
+            self._handle = _capi.Handle(arr, **opts)
+        h = self._handle
+        try:
+            s = h.run()
+            cp, pts = h.state()
+        except Exception:
+            self.close()
+            raise
+        arr.cam_pose[...] = cp
+        arr.points[...] = pts
+        if not self.reuse_device:
+            self.close()
+        return s
 
     # ------------------------------------------------------------------ marshalling
     def _keypoints(self, img_id, kp):
@@ -96,8 +138,8 @@ class BASession:
         try:
             if n_o and (arr.obs_pt.min() < 0 or arr.obs_pt.max() >= n_p):
                 raise KeyError(int(arr.obs_pt.max()))
-            s = _capi.solve(arr, loss="huber", f_scale=float(f_scale), max_iter=int(max_nfev),
-                            ftol=1e-8, xtol=1e-8, gtol=1e-8, verbose=2 if verbose else 0)
+            s = self._run(arr, loss="huber", f_scale=float(f_scale), max_iter=int(max_nfev),
+                          ftol=1e-8, xtol=1e-8, gtol=1e-8, verbose=2 if verbose else 0)
             self.last_summary = _ba.last_summary = s
             if not (s["status"] > 0 or s["final_cost"] < s["residual_sum"] * 0.95):
                 if verbose:

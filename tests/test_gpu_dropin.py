@@ -110,6 +110,8 @@ def test_session_path_equals_module_functions(gpu):
             assert d2[cid][0].dtype == np.float64 and d2[cid][1].shape == (3, 1)
             assert d2[cid][3] is image_data[cid][3] or d2[cid][3] == image_data[cid][3]
     assert sess.last_summary["status"] > 0
+    assert sess.handle_reuses == 1        # inter_ba on the structure final_ba analysed: ba_set_values, no new handle
+    sess.close()
 
 
 def test_opt_in_point_culling(gpu):

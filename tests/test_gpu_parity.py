@@ -194,6 +194,55 @@ def test_banded_and_dense_cholesky_agree(gpu):
     assert np.allclose(out["banded_cholesky"][1].cam_pose, out["dense_cholesky"][1].cam_pose, rtol=1e-6, atol=1e-7)
 
 
+def test_set_values_reuses_the_structure(gpu):
+    """SURVEY 8(f) f1 (device-resident reuse): ba_set_values on a handle that has already solved problem A gives,
+    for new values B on the same structure, the reduced system and the solution of a fresh handle on B; a problem
+    with another structure is refused."""
+    pa = synthetic.make_street(40, 1800, 8000, seed=5, outlier_frac=0.02)
+    rng = np.random.default_rng(9)
+    pb = dict(pa)
+    pb["cam_pose"] = pa["cam_pose"] + 1e-3 * rng.standard_normal(pa["cam_pose"].shape)
+    pb["cam_intr"] = pa["cam_intr"] * (1.0 + 1e-3 * rng.standard_normal(pa["cam_intr"].shape))
+    pb["points"] = pa["points"] + 1e-2 * rng.standard_normal(pa["points"].shape)
+    pb["obs_xy"] = pa["obs_xy"] + 0.3 * rng.standard_normal(pa["obs_xy"].shape)
+    kw = dict(loss="huber", f_scale=1.0, max_iter=40)
+    with _capi.Handle(_capi.Arrays.from_dict(pa), **kw) as h, _capi.Handle(_capi.Arrays.from_dict(pb), **kw) as fresh:
+        sa = h.run()
+        assert sa["iterations"] > 0
+        h.set_values(_capi.Arrays.from_dict(pb))
+        h.build(1e-3); fresh.build(1e-3)
+        ra, rb = h.reduced_system(), fresh.reduced_system()
+        for k in ("S", "gred", "U", "gc", "V", "gp"):
+            assert rel(ra[k], rb[k]) < 1e-11, k
+        # options given to set_values replace the handle's
+        h.set_values(_capi.Arrays.from_dict(pb), loss="huber", f_scale=1.0, max_iter=40)
+        fresh.set_values(_capi.Arrays.from_dict(pb))
+        s1, s2 = h.run(), fresh.run()
+        assert s1["status"] == s2["status"] and s1["iterations"] == s2["iterations"]
+        assert s1["initial_cost"] == s2["initial_cost"]                   # (deterministic cost reduction)
+        assert abs(s1["final_cost"] - s2["final_cost"]) <= 1e-9 * s2["final_cost"]
+        assert s1["pcg_iterations"] == s2["pcg_iterations"] or s1["pcg_iterations"] > 0
+        np.testing.assert_allclose(h.state()[0], fresh.state()[0], rtol=1e-6, atol=1e-8)
+        assert s1["t_setup_ms"] < 0.5 * sa["t_setup_ms"] or sa["t_setup_ms"] < 2.0
+        # another structure: refused, handle unchanged
+        pc = dict(pb)
+        pc["obs_cam"] = pb["obs_cam"].copy()
+        k = int(np.flatnonzero(pc["obs_cam"] != pc["obs_cam"][0])[0])
+        pc["obs_cam"][[0, k]] = pc["obs_cam"][[k, 0]]
+        with pytest.raises(_capi.BaError) as ei:
+            h.set_values(_capi.Arrays.from_dict(pc))
+        assert ei.value.code == _capi.BA_ERR_INVALID
+        pd = dict(pb)
+        pd["cam_fixed"] = np.array(pb["cam_fixed"]).copy(); pd["cam_fixed"][np.flatnonzero(pd["cam_fixed"] == 0)[-1]] = 1
+        with pytest.raises(_capi.BaError):
+            h.set_values(_capi.Arrays.from_dict(pd))
+        pe = dict(pb)
+        pe["points"] = np.concatenate([pb["points"], np.zeros((1, 3))])
+        with pytest.raises(_capi.BaError):
+            h.set_values(_capi.Arrays.from_dict(pe))
+        assert abs(h.cost() - s1["final_cost"]) <= 1e-9 * s1["final_cost"]
+
+
 def test_order_invariance_and_chunk_boundaries(gpu):
     """Shuffling the caller's observation / point order must not change the objective or the
     reduced system (the engine re-sorts internally); sizes straddle chunk boundaries."""
