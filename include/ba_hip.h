@@ -34,12 +34,13 @@ extern "C" {
 #define BA_OK 0
 #define BA_ERR_INVALID (-1)     /* bad argument (null pointer, index out of range, ...) */
 #define BA_ERR_HIP (-2)         /* a HIP runtime call failed / no device */
-#define BA_ERR_UNSUPPORTED (-3) /* e.g. a point with more than BA_MAX_TRACK observations */
+#define BA_ERR_UNSUPPORTED (-3) /* e.g. more than 2e9 observations per handle */
 #define BA_ERR_NOMEM (-4)
 #define BA_ERR_NUMERIC (-5)     /* non-finite initial cost */
 #define BA_ERR_COMM (-6)        /* the all-reduce callback reported a failure */
 
-#define BA_MAX_TRACK 256 /* longest supported track (observations of one point) */
+#define BA_MAX_TRACK 256 /* longest track on the fused chunk path; longer tracks ("heavy points") are eliminated by their
+                            own, slower kernels (one workgroup per point), any length */
 
 /* loss kinds = what scipy.optimize.least_squares accepts (scipy _lsq/least_squares.py:208-209);
  * the reference only uses 'huber' (BundleAdjustment.py:332, :367). */
@@ -104,7 +105,7 @@ typedef struct BaSummary {
 typedef struct BaAnalysis {
     int64_t n_chunks, n_pair_entries, nnz_blocks_upper, nnz_blocks_full;
     int64_t n_direct_pairs, n_direct_cam_obs; /* contributions that bypass the LDS tiles */
-    int32_t n_free_cams, n_observed_points, max_track, max_chunk_cams, max_chunk_pairs, reserved;
+    int32_t n_free_cams, n_observed_points, max_track, max_chunk_cams, max_chunk_pairs, n_heavy_points;
     double mean_track;
 } BaAnalysis;
 

@@ -279,16 +279,18 @@ def reduced_system(nb, cam_fixed, obs_cam, obs_pt, lam):
         gred[o:o + 6] += gc[c]
     order = np.argsort(obs_pt, kind="stable")
     starts = np.searchsorted(obs_pt[order], np.arange(Np + 1))
+    six = np.arange(6)
     for p in range(Np):
         idx = order[starts[p]:starts[p + 1]]
         idx = idx[cam_off[obs_cam[idx]] >= 0]
-        for a in idx:
-            oa = cam_off[obs_cam[a]]
-            Ya = W[a] @ Vinv[p]
-            gred[oa:oa + 6] -= Ya @ gp[p]
-            for b in idx:
-                ob = cam_off[obs_cam[b]]
-                S[oa:oa + 6, ob:ob + 6] -= Ya @ W[b].T
+        if len(idx) == 0:
+            continue
+        # all (a, b) pairs of the point's observations at once: S[a-block, b-block] -= W_a Vinv W_b^T
+        rows = (cam_off[obs_cam[idx]][:, None] + six[None, :]).reshape(-1)
+        Y = W[idx] @ Vinv[p]                                   # (L, 6, 3)
+        np.subtract.at(gred, rows, (Y @ gp[p]).reshape(-1))
+        blocks = np.einsum("aik,bjk->aibj", Y, W[idx]).reshape(len(rows), len(rows))
+        np.subtract.at(S, (rows[:, None], rows[None, :]), blocks)   # (.at: a camera may see the point twice)
     return S, gred, Vinv, Dc, Dp
 
 

@@ -64,7 +64,7 @@ class BaAnalysis(C.Structure):
     _fields_ = [("n_chunks", C.c_int64), ("n_pair_entries", C.c_int64), ("nnz_blocks_upper", C.c_int64),
                 ("nnz_blocks_full", C.c_int64), ("n_direct_pairs", C.c_int64), ("n_direct_cam_obs", C.c_int64),
                 ("n_free_cams", C.c_int32), ("n_observed_points", C.c_int32), ("max_track", C.c_int32),
-                ("max_chunk_cams", C.c_int32), ("max_chunk_pairs", C.c_int32), ("reserved", C.c_int32),
+                ("max_chunk_cams", C.c_int32), ("max_chunk_pairs", C.c_int32), ("n_heavy_points", C.c_int32),
                 ("mean_track", C.c_double)]
 
     def as_dict(self):

@@ -19,6 +19,7 @@
 #include "ba_banded.h"
 #include "ba_dense.h"
 #include "ba_kernels.h"
+#include "ba_heavy.h"
 
 namespace {
 
@@ -131,7 +132,7 @@ struct BaHandle {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
-    int n_chunks = 0, n_upper = 0, n_full = 0;
+    int n_chunks = 0, n_heavy = 0, n_upper = 0, n_full = 0;
     double lambda_host = 0.0;
     bool pattern_uploaded = false;
     double x2_const = 0.0;  // |x|^2 of the unobserved points (never change)
@@ -147,6 +148,10 @@ struct BaHandle {
     DevBuf<double> o_xy;
     DevBuf<long long> ck_pe;
     DevBuf<int> ck_pgrp;
+    // heavy points (ba_heavy.h)
+    DevBuf<long long> hv_obs, hv_pair;
+    DevBuf<int> hv_pair_slot;
+    DevBuf<double> hv_t;
     DevBuf<unsigned> pair_entries;
     // reduced system: one contiguous buffer [S | U | gc | gred | sums(4)]
     DevBuf<double> red;
@@ -194,6 +199,7 @@ int upload_pattern(BaHandle *h) {
     h->n_full = (int)s.bsr_col.size();
     const int nf = s.n_free;
     HIPCHK(h->ck_pair_slot.upload(s.ck_pair_slot, st));
+    HIPCHK(h->hv_pair_slot.upload(s.hv_pair_slot, st));
     HIPCHK(h->diag_slot.upload(s.diag_slot, st));
     HIPCHK(h->bsr_row.upload(s.bsr_row, st));
     HIPCHK(h->bsr_col.upload(s.bsr_col, st));
@@ -251,6 +257,17 @@ BuildArgs build_args(BaHandle *h) {
     return A;
 }
 
+HeavyArgs heavy_args(BaHandle *h) {
+    HeavyArgs H{};
+    H.n_chunks = h->n_chunks;
+    H.pt0 = h->sym.n_pts_chunked;
+    H.hv_obs = h->hv_obs.p;
+    H.hv_pair = h->hv_pair.p;
+    H.hv_pair_slot = h->hv_pair_slot.p;
+    H.hv_t = h->hv_t.p;
+    return H;
+}
+
 // (x, lambda on device) -> cost, S, g_red, block-Jacobi inverse.  Timed pieces: ev0..ev1 fused kernel.
 int do_build(BaHandle *h, bool timed) {
     if (!h->pattern_uploaded) {
@@ -272,7 +289,8 @@ int do_build(BaHandle *h, bool timed) {
         }
     }
     if (timed) HIPCHK(hipEventRecord(h->ev1, st));
-    hipLaunchKernelGGL(k_chunk_totals, dim3(1), dim3(1024), 0, st, h->n_chunks, h->ck_cost.p, h->ck_gmax.p, h->sums, h->gm2.p);
+    if (h->n_heavy > 0) hipLaunchKernelGGL(k_build_heavy, dim3(h->n_heavy), dim3(256), 0, st, build_args(h), heavy_args(h));
+    hipLaunchKernelGGL(k_chunk_totals, dim3(1), dim3(1024), 0, st, h->n_chunks + h->n_heavy, h->ck_cost.p, h->ck_gmax.p, h->sums, h->gm2.p);
     if (h->world > 1) {
         // ONE collective per build: the maximum over ranks of the point-gradient norm rides in the sum buffer,
         // each rank's value in its own slot of the tail (zero elsewhere), and is maximised locally afterwards
@@ -397,7 +415,7 @@ int do_step(BaHandle *h) {
     const int cur = h->cur, tr = cur ^ 1;
     hipLaunchKernelGGL(k_cam_update, dim3((s.n_cams + 63) / 64), dim3(64), 0, st, s.n_cams, h->cam_free.p, h->pose[cur].p,
                        h->intr.p, h->px.p, h->pose[tr].p, h->aux[tr].p, h->cam_part.p);
-    if (h->n_chunks > 0) {
+    if (h->n_chunks + h->n_heavy > 0) {
         BacksubArgs B{};
         B.aux = h->aux[cur].p; B.aux_t = h->aux[tr].p;
         B.points = h->points[cur].p; B.points_t = h->points[tr].p;
@@ -411,9 +429,10 @@ int do_step(BaHandle *h) {
         B.state = h->state.p;
         B.inv_fs2 = 1.0 / (h->opt.f_scale * h->opt.f_scale);
         B.half_fs2 = 0.5 * h->opt.f_scale * h->opt.f_scale;
-        hipLaunchKernelGGL(k_backsub, dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, B);
+        if (h->n_chunks > 0) hipLaunchKernelGGL(k_backsub, dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, B);
+        if (h->n_heavy > 0) hipLaunchKernelGGL(k_backsub_heavy, dim3(h->n_heavy), dim3(256), 0, st, B, heavy_args(h));
     }
-    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(1024), 0, st, h->n_chunks, 4, h->ck_part.p, h->step_sums.p);
+    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(1024), 0, st, h->n_chunks + h->n_heavy, 4, h->ck_part.p, h->step_sums.p);
     hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(1024), 0, st, s.n_cams, 2, h->cam_part.p, h->cam_sums.p);
     // |x|^2 of this rank's unobserved points joins the partial sums BEFORE the all-reduce so that
     // every rank takes the same decision
@@ -514,6 +533,13 @@ int create_impl(const BaProblem *prob, const BaOptions *opt, BaHandle *h) {
     Symbolic &s = h->sym;
     hipStream_t st = h->stream;
     h->n_chunks = (int)s.ck_obs.size() - 1;
+    h->n_heavy = s.n_heavy;
+    if (s.n_heavy > 0) {
+        std::vector<long long> ho(s.hv_obs.begin(), s.hv_obs.end()), hq(s.hv_pair.begin(), s.hv_pair.end());
+        HIPCHK(h->hv_obs.upload(ho, st));
+        HIPCHK(h->hv_pair.upload(hq, st));
+        HIPCHK(h->hv_t.alloc((size_t)(s.hv_obs.back() - s.hv_obs.front()) * 18));
+    }
     for (int b = 0; b < 2; ++b) HIPCHK(h->aux[b].alloc((size_t)s.n_cams * BA_CAM_AUX));
     HIPCHK(h->cam_free.upload(s.cam_free, st));
     HIPCHK(h->o_cam.upload(s.o_cam, st));
@@ -538,9 +564,9 @@ int create_impl(const BaProblem *prob, const BaOptions *opt, BaHandle *h) {
     HIPCHK(h->gm2.alloc(2));
     HIPCHK(h->pt_linv.alloc((size_t)s.n_pts_obs * 6));
     HIPCHK(h->pt_u.alloc((size_t)s.n_pts_obs * 3));
-    HIPCHK(h->ck_cost.alloc((size_t)h->n_chunks));
-    HIPCHK(h->ck_gmax.alloc((size_t)h->n_chunks));
-    HIPCHK(h->ck_part.alloc((size_t)h->n_chunks * 4));
+    HIPCHK(h->ck_cost.alloc((size_t)(h->n_chunks + h->n_heavy)));
+    HIPCHK(h->ck_gmax.alloc((size_t)(h->n_chunks + h->n_heavy)));
+    HIPCHK(h->ck_part.alloc((size_t)(h->n_chunks + h->n_heavy) * 4));
     HIPCHK(h->cam_part.alloc((size_t)s.n_cams * 2));
     HIPCHK(h->step_sums.alloc(4));
     HIPCHK(h->cam_sums.alloc(2));
@@ -1004,6 +1030,7 @@ int ba_analyze(const BaProblem *prob, BaAnalysis *out) {
     out->n_free_cams = s.n_free;
     out->n_observed_points = s.n_pts_obs;
     out->max_track = s.max_track;
+    out->n_heavy_points = s.n_heavy;
     out->max_chunk_cams = s.max_chunk_cams;
     out->max_chunk_pairs = s.max_chunk_pairs;
     out->mean_track = s.mean_track;

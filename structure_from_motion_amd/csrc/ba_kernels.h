@@ -207,7 +207,7 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
                 for (int i = 0; i < 6; ++i) {
 #pragma unroll
                     for (int j = i; j < 6; ++j) atomicAdd(&up[ut6(i, j)], wJc[0][i] * L.Jc[0][j] + wJc[1][i] * L.Jc[1][j]);
-                    atomicAdd(&gp[i], wJc[0][i] * L.r[0] + wJc[1][i] * L.r[1]);
+                    atomicAdd(&gp[i], L.Jc[0][i] * wr0 + L.Jc[1][i] * wr1);  // gradient weights w, not the curvature weights
                 }
             }
         }

@@ -49,12 +49,16 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
     s.pt_order.resize(n_points);
     {
         std::vector<int32_t> tmp(n_points), head(n_cams + 2);
-        int n_obs_pts = 0;
+        int n_obs_pts = 0, n_heavy = 0;  // (n_obs_pts: the points that go into chunks)
         for (int i = 0; i < n_points; ++i)
-            if (cnt[i] > 0) tmp[n_obs_pts++] = i;
+            if (cnt[i] > 0 && cnt[i] <= CHUNK_OBS) tmp[n_obs_pts++] = i;
         int n_un = n_obs_pts;
         for (int i = 0; i < n_points; ++i)
+            if (cnt[i] > CHUNK_OBS) s.pt_order[n_un++] = i, ++n_heavy;  // heavy points: own kernels, after the chunked ones
+        for (int i = 0; i < n_points; ++i)
             if (cnt[i] == 0) s.pt_order[n_un++] = i;  // unobserved points last, in index order
+        s.n_pts_chunked = n_obs_pts;
+        s.n_heavy = n_heavy;
         auto pass = [&](const std::vector<int32_t> &key, const int32_t *src, int32_t *dst) {
             std::fill(head.begin(), head.end(), 0);
             for (int i = 0; i < n_obs_pts; ++i) head[key[src[i]] + 1]++;
@@ -97,10 +101,6 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
         s.max_track = std::max(s.max_track, L);
         track_sum += L;
     }
-    if (s.max_track > CHUNK_OBS) {
-        *err = "a point has more than BA_MAX_TRACK observations";
-        return BA_ERR_UNSUPPORTED;
-    }
     tick("obs gather");
     // --- greedy chunking -----------------------------------------------------------------
     std::vector<int32_t> cam_stamp(std::max(s.n_free, 1), -1), cam_slot(std::max(s.n_free, 1), 0);
@@ -129,7 +129,7 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
     s.cs_obs.assign((size_t)n_obs, 0);
     {
         double est = 0;  // pair entries: sum of L (L + 1) / 2, plus the padding of the groups
-        for (int i = 0; i < s.n_pts_obs; ++i) {
+        for (int i = 0; i < s.n_pts_chunked; ++i) {
             const double L = (double)(pstart[i + 1] - pstart[i]);
             est += 0.5 * L * (L + 1);
         }
@@ -195,7 +195,7 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
         obs_base = next_obs;
     };
     std::vector<int32_t> fidx;
-    for (int i = 0; i < s.n_pts_obs; ++i) {
+    for (int i = 0; i < s.n_pts_chunked; ++i) {
         const int64_t b = pstart[i], e = pstart[i + 1];
         const int L = (int)(e - b);
         fidx.resize(L);
@@ -269,8 +269,33 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
         cur_obs += L;
         cur_pts += 1;
     }
-    if (cur_pts > 0) close_chunk(s.n_pts_obs, pstart[s.n_pts_obs]);
+    if (cur_pts > 0) close_chunk(s.n_pts_chunked, pstart[s.n_pts_chunked]);
     tick("chunking");
+    // --- heavy points (more observations than a chunk holds): one workgroup each (k_build_heavy), every (a <= c)
+    // pair of the point's observations gets its block slot from a triangular list
+    s.hv_obs.push_back(pstart[s.n_pts_chunked]);
+    s.hv_pair.push_back(0);
+    for (int i = s.n_pts_chunked; i < s.n_pts_chunked + s.n_heavy; ++i) {
+        const int64_t b = pstart[i], e = pstart[i + 1];
+        const int L = (int)(e - b);
+        for (int a = 0; a < L; ++a) {
+            const int fa = s.cam_free[s.o_cam[b + a]];
+            s.o_lcam[b + a] = fa < 0 ? -2 : -1;
+            for (int c = a; c < L; ++c) {
+                const int fc = s.cam_free[s.o_cam[b + c]];
+                int64_t key = -1;
+                if (fa >= 0 && fc >= 0) {
+                    key = ((int64_t)std::min(fa, fc) << 32) | (uint32_t)std::max(fa, fc);
+                    if (fa > fc) key |= HV_KEY_TRANSPOSED;
+                    if (fa == fc && a != c) key |= HV_KEY_TWICE;
+                }
+                s.hv_keys.push_back(key);
+            }
+        }
+        s.hv_obs.push_back(e);
+        s.hv_pair.push_back((int64_t)s.hv_keys.size());
+    }
+    tick("heavy points");
     // (the build kernel prefetches one round of entries unconditionally: readable padding behind the last chunk)
     s.pair_entries.resize(s.pair_entries.size() + (size_t)(CHUNK_OBS / 2) * PAIR_RUN, PAIR_NULL);
     // slots are resolved by finalize_pattern (the pattern may be a union over ranks)
@@ -284,12 +309,23 @@ void finalize_pattern(Symbolic &s, const std::vector<int64_t> &extra_keys) {
     const std::vector<int64_t> &raw = s.raw_keys;  // per-chunk keys, same order as ck_pair_slot
     std::vector<int64_t> keys(raw);
     keys.insert(keys.end(), extra_keys.begin(), extra_keys.end());
+    for (int64_t k : s.hv_keys)
+        if (k >= 0) keys.push_back(k & HV_KEY_MASK);
     for (int f = 0; f < s.n_free; ++f) keys.push_back(((int64_t)f << 32) | (uint32_t)f);  // every diagonal block
     std::sort(keys.begin(), keys.end());
     keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
     s.upper_keys = keys;
     for (size_t k = 0; k < raw.size(); ++k)
         s.ck_pair_slot[k] = (int32_t)(std::lower_bound(keys.begin(), keys.end(), raw[k]) - keys.begin());
+    s.hv_pair_slot.assign(s.hv_keys.size(), -1);
+    for (size_t k = 0; k < s.hv_keys.size(); ++k) {
+        const int64_t key = s.hv_keys[k];
+        if (key < 0) continue;
+        int32_t slot = (int32_t)(std::lower_bound(keys.begin(), keys.end(), key & HV_KEY_MASK) - keys.begin());
+        if (key & HV_KEY_TRANSPOSED) slot |= HV_SLOT_TRANSPOSED;
+        if (key & HV_KEY_TWICE) slot |= HV_SLOT_TWICE;
+        s.hv_pair_slot[k] = slot;
+    }
     // full CSR view
     const int nf = s.n_free;
     s.diag_slot.assign(nf, -1);

@@ -21,8 +21,16 @@ constexpr int CHUNK_CAMS = 28;   // cameras with an LDS tile per chunk
 constexpr int PAIR_RUN = 8;      // pair entries per group = per lane pair of the build kernel (see Symbolic::pair_entries)
 constexpr uint32_t PAIR_NULL = 0xFFFFFFFFu;  // padding entry (local pair ids stay below 0xFFFF: at most 256 * 257 / 2 pairs)
 
+// heavy points (tracks longer than CHUNK_OBS): flags on the pair keys (free-camera indices stay below 2^30) and on the
+// resolved block slots (fewer than 2^29 blocks)
+constexpr int64_t HV_KEY_TRANSPOSED = (int64_t)1 << 62, HV_KEY_TWICE = (int64_t)1 << 61;
+constexpr int64_t HV_KEY_MASK = ~(HV_KEY_TRANSPOSED | HV_KEY_TWICE);
+constexpr int32_t HV_SLOT_TRANSPOSED = 1 << 30, HV_SLOT_TWICE = 1 << 29, HV_SLOT_MASK = (1 << 29) - 1;
+
 struct Symbolic {
     int n_cams = 0, n_free = 0, n_points = 0, n_pts_obs = 0;
+    int n_pts_chunked = 0;           // internal points [0, n_pts_chunked) are covered by chunks,
+    int n_heavy = 0;                 // [n_pts_chunked, n_pts_chunked + n_heavy) are heavy, the rest (up to n_pts_obs .. n_points) unobserved
     int64_t n_obs = 0;
     int max_track = 0;
     double mean_track = 0;
@@ -48,6 +56,12 @@ struct Symbolic {
                                         // of PAIR_RUN words of one pair, PAIR_NULL-padded; per chunk whole rounds of CHUNK_OBS/2 groups
     std::vector<int32_t> ck_pgrp;       // per chunk (n_local_pairs + 1) group offsets, at ck_pair[ck] + ck
     int64_t n_pair_real = 0;            // entries that are not padding
+    // heavy points: observation ranges, and per point the triangular list of (a <= c) observation pairs
+    std::vector<int64_t> hv_obs;        // [n_heavy+1] internal observation range of each heavy point
+    std::vector<int64_t> hv_pair;       // [n_heavy+1] into hv_keys / hv_pair_slot; row a of a point with L observations
+                                        // starts at a L - a (a - 1) / 2, entry (a, c) sits at row start + (c - a)
+    std::vector<int64_t> hv_keys;       // (min<<32 | max) | flags, or -1 when one of the two cameras is fixed
+    std::vector<int32_t> hv_pair_slot;  // block slot | HV_SLOT_* flags, or -1
     // reduced camera system pattern
     std::vector<int64_t> upper_keys; // sorted unique (i<<32 | j), i <= j, free-camera indices
     std::vector<int32_t> diag_slot;  // [n_free]

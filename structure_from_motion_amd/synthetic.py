@@ -111,14 +111,16 @@ def make_street(n_cams, n_points, n_obs, seed=0, noise=0.5, outlier_frac=0.01, m
 
 def make_ring(n_cams, n_points, seed=0, K=(1520.4, 1525.9, 302.32, 246.87), focal_jitter=0.02,
               noise=0.35, outlier_frac=0.0, visibility="dense", mean_track=4.0, n_fixed=1,
-              n_seed_points=None, radius=4.0, sig_r=1e-3, sig_t=1e-2, sig_p=1e-2, n_unobserved=0):
+              n_seed_points=None, radius=4.0, sig_r=1e-3, sig_t=1e-2, sig_p=1e-2, n_unobserved=0,
+              max_track=24, n_landmarks=0):
     """Temple / Fountain-shaped problem: cameras on a ring (or arc) of ``radius`` looking at a
     unit blob of points.
 
     visibility='dense': each point is seen by a contiguous window of ring cameras (mean length
     ``mean_track``).  visibility='sfm': what the reference's driver actually produces
     (SURVEY.md H4): the first ``n_seed_points`` points have 2 observations (cameras 0 and 1),
-    every other point exactly 1 (``Reconstruction.py:41-47, 244-251``)."""
+    every other point exactly 1 (``Reconstruction.py:41-47, 244-251``).
+    ``n_landmarks`` (dense only): the first points are seen by EVERY camera (tracks of ``n_cams``)."""
     rng = np.random.default_rng(seed)
     ang = np.linspace(0.0, 2 * np.pi, n_cams, endpoint=False) if n_cams > 12 else np.linspace(-0.9, 0.9, n_cams)
     C = np.stack([radius * np.sin(ang), rng.normal(0, 0.05, n_cams), -radius * np.cos(ang)], axis=1)
@@ -136,7 +138,8 @@ def make_ring(n_cams, n_points, seed=0, K=(1520.4, 1525.9, 302.32, 246.87), foca
     points_gt = rng.normal(0.0, 0.45, size=(n_points, 3))
     if visibility == "dense":
         n_obs = int(round(mean_track * n_obs_pts))
-        L = _track_lengths(rng, n_obs_pts, n_obs, max_track=min(n_cams, 24))
+        L = _track_lengths(rng, n_obs_pts, n_obs, max_track=min(n_cams, max_track))
+        L[:n_landmarks] = n_cams
         # window centred on the camera nearest to the point's azimuth
         az = np.arctan2(points_gt[:n_obs_pts, 0], -points_gt[:n_obs_pts, 2])
         near = np.argmin(np.abs(((az[:, None] - ang[None, :] + np.pi) % (2 * np.pi)) - np.pi), axis=1)

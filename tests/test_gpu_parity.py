@@ -243,6 +243,39 @@ def test_set_values_reuses_the_structure(gpu):
         assert abs(h.cost() - s1["final_cost"]) <= 1e-9 * s1["final_cost"]
 
 
+def test_heavy_points_and_slotless_cameras(gpu):
+    """Tracks longer than a chunk (3 landmarks seen by all 270 cameras: heavy-point kernels) next to windows of up to
+    60 cameras (more than a chunk has LDS camera tiles: the slot-less path), 5 % outliers: reduced system against the
+    oracle, then the LM trajectory against the oracle's (the curvature floor drops below 1 on the way, so gradient
+    and curvature weights differ)."""
+    p = synthetic.make_ring(270, 110, seed=3, mean_track=30.0, max_track=60, n_landmarks=3, outlier_frac=0.05, n_fixed=2,
+                            n_unobserved=2)
+    arr = _capi.Arrays.from_dict(p)
+    a = _capi.analyze(arr)
+    assert a["n_heavy_points"] == 3 and a["max_track"] == 270 and a["n_direct_cam_obs"] > 0
+    lam = 1e-3
+    nb = O.normal_blocks(*oracle_args(p), p["obs_xy"], 1.0, "huber", floor=1.0)
+    S, gred, _, _, _ = O.reduced_system(nb, p["cam_fixed"], p["obs_cam"], p["obs_pt"], lam)
+    with _capi.Handle(arr, loss="huber", f_scale=1.0) as h:
+        h.build(lam)
+        r = h.reduced_system()
+        free = p["cam_fixed"] == 0
+        assert rel(r["U"][free], nb["U"][free]) < 1e-12 and rel(r["gc"][free], nb["gc"][free]) < 1e-11
+        assert rel(r["V"], nb["V"]) < 1e-12 and rel(r["gp"], nb["gp"]) < 1e-11
+        assert rel(r["S"], S) < 1e-9 and rel(r["gred"], gred) < 1e-9
+        assert abs(h.cost() - nb["F"]) <= 1e-12 * nb["F"]
+    res = O.lm_solve(p["cam_pose"], p["cam_intr"], p["cam_fixed"], p["points"], p["obs_cam"], p["obs_pt"],
+                     p["obs_xy"], f_scale=1.0, max_iter=12)
+    s = _capi.solve(arr, loss="huber", f_scale=1.0, max_iter=12, linear_solver="dense_cholesky")
+    assert s["status"] == res["status"] and abs(s["iterations"] - res["iterations"]) <= 1
+    assert abs(s["initial_cost"] - res["history"][0][1]) <= 1e-12 * s["initial_cost"]
+    assert abs(s["final_cost"] - res["cost"]) <= 1e-7 * res["cost"]
+    assert s["final_cost"] < 0.2 * s["initial_cost"]
+    np.testing.assert_allclose(arr.points, res["points"], rtol=0, atol=1e-6)
+    unobs = np.setdiff1d(np.arange(len(p["points"])), p["obs_pt"])
+    np.testing.assert_array_equal(arr.points[unobs], p["points"][unobs])
+
+
 def test_order_invariance_and_chunk_boundaries(gpu):
     """Shuffling the caller's observation / point order must not change the objective or the
     reduced system (the engine re-sorts internally); sizes straddle chunk boundaries."""
@@ -293,7 +326,7 @@ def test_edge_cases(gpu):
         h.build(1e-2)
         r = h.reduced_system(want_points=False)
         assert rel(r["S"], S) < 1e-10 and rel(r["gred"], gred) < 1e-9
-    # bad index -> error code, no crash; long track -> unsupported
+    # bad index -> error code, no crash
     p = dict(base); p["obs_cam"] = base["obs_cam"].copy(); p["obs_cam"][0] = 6
     with pytest.raises(_capi.BaError):
         _capi.solve(_capi.Arrays.from_dict(p))

@@ -78,17 +78,26 @@ def test_structure_analysis(kind):
     assert a["nnz_blocks_full"] == 2 * len(pairs) - a["n_free_cams"]
 
 
-def test_analyze_rejects_bad_indices_and_long_tracks():
+def test_analyze_rejects_bad_indices_and_routes_long_tracks():
     p = synthetic.make_street(6, 40, 160, seed=1)
     bad = dict(p); bad["obs_pt"] = p["obs_pt"].copy(); bad["obs_pt"][3] = 40
     with pytest.raises(_capi.BaError):
         _capi.analyze(_capi.Arrays.from_dict(bad))
+    # a track longer than a chunk (256 observations) is a "heavy point": no chunk, every camera pair in the pattern
     n = 300
     long = dict(cam_pose=np.zeros((n, 6)), cam_intr=np.ones((n, 4)), cam_fixed=np.zeros(n, np.uint8),
                 points=np.zeros((2, 3)), obs_cam=np.arange(n), obs_pt=np.zeros(n, np.int32), obs_xy=np.zeros((n, 2)))
-    with pytest.raises(_capi.BaError) as ei:
-        _capi.analyze(_capi.Arrays.from_dict(long))
-    assert ei.value.code == -3
+    long["cam_fixed"][7] = 1
+    a = _capi.analyze(_capi.Arrays.from_dict(long))
+    assert a["n_heavy_points"] == 1 and a["max_track"] == n and a["n_chunks"] == 0 and a["n_observed_points"] == 1
+    assert a["nnz_blocks_upper"] == (n - 1) * n // 2
+    # 256 is still a chunk; mixed problems keep both kinds
+    p = synthetic.make_ring(270, 40, seed=2, mean_track=12.0, n_landmarks=2)
+    a = _capi.analyze(_capi.Arrays.from_dict(p))
+    assert a["n_heavy_points"] == 2 and a["n_observed_points"] == 40 and a["n_chunks"] >= 2
+    p = synthetic.make_ring(256, 40, seed=2, mean_track=12.0, n_landmarks=2)
+    a = _capi.analyze(_capi.Arrays.from_dict(p))
+    assert a["n_heavy_points"] == 0 and a["max_track"] == 256
 
 
 def test_rodrigues_round_trip_matches_oracle():
