@@ -34,9 +34,12 @@ def make_collective(group=None):
     import torch.distributed as dist
 
     host_staged = dist.get_backend(group) != "nccl"  # e.g. gloo in the single-GPU tests
+    views = {}  # (pointer, count) -> tensor aliasing the library's buffer (the buffers live as long as the handle)
 
     def coll(ptr, count, op):
-        dev = torch.as_tensor(_DevArray(ptr, count), device="cuda")
+        dev = views.get((ptr, count))
+        if dev is None:
+            dev = views[(ptr, count)] = torch.as_tensor(_DevArray(ptr, count), device="cuda")
         t = dev.cpu() if host_staged else dev
         _run(t, op)
         if host_staged:
