@@ -142,8 +142,7 @@ struct BaHandle {
     DevBuf<double> intr;
     DevBuf<int> cam_free;
     // observations, chunks
-    DevBuf<int> o_cam, o_pt, ck_obs, ck_pt, ck_cam, ck_cam_list, ck_pair, ck_pair_slot, ck_cs;
-    DevBuf<unsigned char> cs_obs;
+    DevBuf<int> o_cam, o_pt, ck_obs, ck_pt, ck_cam, ck_cam_list, ck_pair, ck_pair_slot;
     DevBuf<short> o_lcam;
     DevBuf<double> o_xy;
     DevBuf<long long> ck_pe;
@@ -245,13 +244,6 @@ BuildArgs build_args(BaHandle *h) {
     A.dbg_gp = h->dbg_gp.n ? h->dbg_gp.p : nullptr;
     A.state = h->state.p;
     A.loss = h->opt.loss;
-    A.ck_cs = h->ck_cs.p;
-    A.cs_obs = h->cs_obs.p;
-    {
-        int span = 1;
-        while (span < h->sym.max_track && span < 64) span <<= 1;
-        A.seg_span = span;
-    }
     A.inv_fs2 = 1.0 / (h->opt.f_scale * h->opt.f_scale);
     A.half_fs2 = 0.5 * h->opt.f_scale * h->opt.f_scale;
     return A;
@@ -549,8 +541,6 @@ int create_impl(const BaProblem *prob, const BaOptions *opt, BaHandle *h) {
     HIPCHK(h->ck_pt.upload(s.ck_pt, st));
     HIPCHK(h->ck_cam.upload(s.ck_cam, st));
     HIPCHK(h->ck_cam_list.upload(s.ck_cam_list, st));
-    HIPCHK(h->ck_cs.upload(s.ck_cs, st));
-    HIPCHK(h->cs_obs.upload(s.cs_obs, st));
     HIPCHK(h->ck_pair.upload(s.ck_pair, st));
     {
         std::vector<long long> pe(s.ck_pe.begin(), s.ck_pe.end());

@@ -44,8 +44,6 @@ struct BuildArgs {
     const double *o_xy;
     const int *cam_free;
     const int *ck_obs, *ck_pt, *ck_cam, *ck_cam_list, *ck_pair, *ck_pair_slot;
-    const int *ck_cs;               // per chunk (n_local_cams + 1) offsets into cs_obs, at ck_cam[ck] + ck
-    const unsigned char *cs_obs;    // per chunk: its observations (chunk-local index) grouped by local camera
     const long long *ck_pe;
     const int *ck_pgrp;             // per chunk (n_local_pairs + 1) group offsets, at ck_pair[ck] + ck
     const unsigned *pair_entries;
@@ -55,7 +53,6 @@ struct BuildArgs {
     double *dbg_v, *dbg_gp;         // optional [n_pts_obs*6], [n_pts_obs*3]
     const LmState *state;           // lambda is read from here
     int loss;
-    int seg_span;                   // power of two >= longest track (<= 64): span of the segmented wave sums
     double inv_fs2, half_fs2;
     unsigned long long *stamps;     // diagnostic build only
 };
@@ -97,18 +94,14 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
     __shared__ __attribute__((aligned(16))) double sC[CHUNK_CAMS * 33];  // per local camera: U(21) g_c(6) g_red part(6)
     __shared__ double sRed[4];
     __shared__ unsigned char sLp[CHUNK_OBS];                             // local point of each observation
-    __shared__ unsigned char sCs[CHUNK_OBS];                             // observations grouped by local camera
     __shared__ unsigned char sLc[CHUNK_OBS];                             // local camera of each observation
-    __shared__ int sCsStart[CHUNK_CAMS + 1];
     __shared__ int sPg[CHUNK_OBS / 2 + 2], sSlot[CHUNK_OBS / 2 + 1];    // group offsets / S block slots of the first pairs
-    // (phase 1 stages sqrt(w) Jc (2x6) and sqrt(w) r (2) per observation in sT, which is idle until phase 2b)
 
-    const int ck = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int ck = blockIdx.x, tid = threadIdx.x;
     const int ob = A.ck_obs[ck], nobs = A.ck_obs[ck + 1] - ob;
     const int pb = A.ck_pt[ck], npts = A.ck_pt[ck + 1] - pb;
     const int cb = A.ck_cam[ck], ncam = A.ck_cam[ck + 1] - cb;
     const int qb = A.ck_pair[ck], npair = A.ck_pair[ck + 1] - qb;
-    const int csb = cb + ck;
     const double lam = A.state->lambda;
 
     BA_STAMP(0);
@@ -120,8 +113,6 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
     //   3. its camera block and point (dependent on 2; only phase 1, after the barrier, waits for them).
     const bool act = tid < nobs;
     const int oo = ob + (act ? tid : 0);
-    const unsigned char st_cs = A.cs_obs[oo];
-    const int st_start = A.ck_cs[csb + (tid <= ncam ? tid : 0)];
     const bool has_pg = tid <= npair && tid <= CHUNK_OBS / 2, has_slot = tid < npair && tid <= CHUNK_OBS / 2;
     const int st_pg = A.ck_pgrp[qb + ck + (has_pg ? tid : 0)];  // (pairs beyond CHUNK_OBS / 2 hold no first-round group)
     const int st_slot = A.ck_pair_slot[has_slot ? qb + tid : 0];
@@ -147,8 +138,6 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
     const double floor_now = A.state->floor;
     for (int i = tid; i < npts * 9; i += CHUNK_OBS) sP[i] = 0.0;
     for (int i = tid; i < ncam * 33; i += CHUNK_OBS) sC[i] = 0.0;
-    if (act) sCs[tid] = st_cs;
-    if (tid <= ncam) sCsStart[tid] = st_start;
     if (has_pg) sPg[tid] = st_pg;
     if (has_slot) sSlot[tid] = st_slot;
     __syncthreads();
@@ -159,11 +148,10 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
     double vs[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) vs[k] = 0.0;
-    int lp = 0, lc = -2, fcam = -1, key = -1 - tid;
+    int lp = 0, lc = -2, fcam = -1;
     double cost_loc = 0.0;
     if (act) {
         lp = p - pb;
-        key = lp;
         sLp[tid] = (unsigned char)lp;
         lc = lc_ld;
         sLc[tid] = (unsigned char)lc;
@@ -192,14 +180,16 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) W[i * 3 + j] = wJc[0][i] * L.Jp[0][j] + wJc[1][i] * L.Jp[1][j];
             if (lc >= 0) {
-                // stage sqrt(w) Jc and sqrt(w) r: the per-camera sums are gathered below, without atomics
-                const double q0 = rsqrt_nr(L.wh[0]), q1 = rsqrt_nr(L.wh[1]);  // wh > 0
-                const double s0 = L.wh[0] * q0, s1 = L.wh[1] * q1;
-                double *js = &sT[tid * 18];
+                // per-camera U (21) and g_c (6): LDS atomics into the camera's tile.  (A gather through a camera-sorted
+                // observation list, without atomics, won at two workgroups per CU; at three the VALU is the scarcer
+                // unit and the plain atomics are faster.)
+                double *cp = &sC[lc * 33];
 #pragma unroll
-                for (int i = 0; i < 6; ++i) { js[i] = s0 * L.Jc[0][i]; js[6 + i] = s1 * L.Jc[1][i]; }
-                js[12] = wr0 * q0;  // Js^T rs = Jc^T (w r)
-                js[13] = wr1 * q1;
+                for (int i = 0; i < 6; ++i) {
+#pragma unroll
+                    for (int j = i; j < 6; ++j) atomicAdd(&cp[ut6(i, j)], wJc[0][i] * L.Jc[0][j] + wJc[1][i] * L.Jc[1][j]);
+                    atomicAdd(&cp[21 + i], L.Jc[0][i] * wr0 + L.Jc[1][i] * wr1);
+                }
             } else {  // camera without a local slot in this chunk: straight to HBM
                 fcam = A.cam_free[cam];
                 double *up = &A.U[(size_t)fcam * 21], *gp = &A.gc[(size_t)fcam * 6];
@@ -213,70 +203,16 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
         }
     }
     BA_STAMP(2);
-    // per-point sums: the observations of a point sit in adjacent lanes -> segmented wave reduction,
-    // then one LDS add per (wave, point) instead of one per observation
-    {
-        for (int s = 1; s < A.seg_span; s <<= 1) {
-            const int k2 = __shfl_down(key, s, 64);
-            const bool ok = (lane + s < 64) && (k2 == key);
+    // per-point sums V (6), g_p (3): LDS atomics (same reasoning; the segmented wave reduction they replace cost
+    // more VALU and shuffle time than the atomics cost LDS time)
+    if (act) {
+        double *vp = &sP[lp * 9];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                const double t = __shfl_down(vs[k], s, 64);
-                if (ok) vs[k] += t;
-            }
-        }
-        const int kprev = __shfl_up(key, 1, 64);
-        if (act && (lane == 0 || kprev != key)) {
-            double *vp = &sP[lp * 9];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) atomicAdd(&vp[k], vs[k]);
-        }
+        for (int k = 0; k < 9; ++k) atomicAdd(&vp[k], vs[k]);
     }
     __syncthreads();
 
     BA_STAMP(3);
-    // ---- phase 1b: per-camera U = sum Js^T Js, g_c = sum Js^T rs, gathered through the chunk's
-    // camera-sorted observation list: lane = (local camera, row, quarter of its observations)
-    for (int item = tid; item < ncam * 24; item += CHUNK_OBS) {
-        const int l = item / 24, rem = item - l * 24, row = rem >> 2, sl = rem & 3;
-        const int c1 = sCsStart[l + 1];
-        double acc[6], g = 0.0;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) acc[j] = 0.0;
-        for (int k = sCsStart[l] + sl; k < c1; k += 16) {  // four observations per round, loads issued together
-            const double *js[4];
-            double a0[4], a1[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int kk = k + 4 * u;
-                js[u] = &sT[(int)sCs[kk < c1 ? kk : c1 - 1] * 18];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const double wv = (k + 4 * u < c1) ? 1.0 : 0.0;
-                a0[u] = wv * js[u][row];
-                a1[u] = wv * js[u][6 + row];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-#pragma unroll
-                for (int j = 0; j < 6; ++j) acc[j] += a0[u] * js[u][j] + a1[u] * js[u][6 + j];
-                g += a0[u] * js[u][12] + a1[u] * js[u][13];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 6; ++j) { acc[j] += dpp_f64<0xB1>(acc[j]); acc[j] += dpp_f64<0x4E>(acc[j]); }  // quad sums
-        g += dpp_f64<0xB1>(g);
-        g += dpp_f64<0x4E>(g);
-        if (sl == 0) {  // the one owner of these elements: plain stores
-            double *up = &sC[l * 33 + row * 6 - (row * (row - 1)) / 2 - row];
-#pragma unroll
-            for (int j = 0; j < 6; ++j)
-                if (j >= row) up[j] = acc[j];
-            sC[l * 33 + 21 + row] = g;
-        }
-    }
-
     BA_STAMP(4);
     // ---- phase 2a: one point per lane: damp, 3x3 Cholesky, inverse factor in registers ------
     double gmax_loc = 0.0;

@@ -126,7 +126,6 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
     s.ck_pe.push_back(0);
     int chunk = 0, cur_obs = 0, cur_pts = 0, cur_cams = 0;
     int64_t obs_base = 0;
-    s.cs_obs.assign((size_t)n_obs, 0);
     {
         double est = 0;  // pair entries: sum of L (L + 1) / 2, plus the padding of the groups
         for (int i = 0; i < s.n_pts_chunked; ++i) {
@@ -135,16 +134,7 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
         }
         s.pair_entries.reserve((size_t)(est * 1.25) + 4096);
     }
-    std::vector<int32_t> cs_count;
     auto close_chunk = [&](int next_pt, int64_t next_obs) {
-        // observations of the chunk grouped by local camera slot (counting sort)
-        cs_count.assign(cur_cams + 1, 0);
-        for (int64_t o = obs_base; o < next_obs; ++o)
-            if (s.o_lcam[o] >= 0) cs_count[s.o_lcam[o] + 1]++;
-        for (int l = 0; l < cur_cams; ++l) cs_count[l + 1] += cs_count[l];
-        for (int l = 0; l <= cur_cams; ++l) s.ck_cs.push_back(cs_count[l]);
-        for (int64_t o = obs_base; o < next_obs; ++o)
-            if (s.o_lcam[o] >= 0) s.cs_obs[obs_base + cs_count[s.o_lcam[o]]++] = (uint8_t)(o - obs_base);
         s.ck_obs.push_back((int32_t)next_obs);
         s.ck_pt.push_back(next_pt);
         s.ck_cam.push_back((int32_t)s.ck_cam_list.size());

@@ -46,8 +46,6 @@ struct Symbolic {
     std::vector<int32_t> ck_pt;      // [n_chunks+1] (internal point range)
     std::vector<int32_t> ck_cam;     // [n_chunks+1] into ck_cam_list
     std::vector<int32_t> ck_cam_list;   // free-camera index per local slot
-    std::vector<int32_t> ck_cs;         // per chunk (n_local_cams + 1) offsets into cs_obs, stored at ck_cam[ck] + ck
-    std::vector<uint8_t> cs_obs;        // [n_obs] per chunk: chunk-local observation indices grouped by local camera
     std::vector<int32_t> ck_pair;    // [n_chunks+1] into ck_pair_slot
     std::vector<int32_t> ck_pair_slot;  // upper-triangle block slot per local pair
     std::vector<int64_t> raw_keys;      // (i<<32 | j) per local pair, same order as ck_pair_slot
