@@ -92,7 +92,8 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
     __shared__ __attribute__((aligned(16))) double sT[CHUNK_OBS * 18];   // T = W L^-T per observation (6x3)
     __shared__ __attribute__((aligned(16))) double sP[CHUNK_PTS * 9];    // per point: V(6) g_p(3), then L^-1(6) u(3)
     __shared__ __attribute__((aligned(16))) double sC[CHUNK_CAMS * 33];  // per local camera: U(21) g_c(6) g_red part(6)
-    __shared__ double sRed[4];
+    __shared__ double sRed[8];
+    __shared__ int sCam[CHUNK_CAMS];                                     // free-camera index of each local camera
     __shared__ unsigned char sLp[CHUNK_OBS];                             // local point of each observation
     __shared__ unsigned char sLc[CHUNK_OBS];                             // local camera of each observation
     __shared__ int sPg[CHUNK_OBS / 2 + 2], sSlot[CHUNK_OBS / 2 + 1];    // group offsets / S block slots of the first pairs
@@ -113,6 +114,7 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
     //   3. its camera block and point (dependent on 2; only phase 1, after the barrier, waits for them).
     const bool act = tid < nobs;
     const int oo = ob + (act ? tid : 0);
+    const int st_cam = A.ck_cam_list[tid < ncam ? cb + tid : 0];
     const bool has_pg = tid <= npair && tid <= CHUNK_OBS / 2, has_slot = tid < npair && tid <= CHUNK_OBS / 2;
     const int st_pg = A.ck_pgrp[qb + ck + (has_pg ? tid : 0)];  // (pairs beyond CHUNK_OBS / 2 hold no first-round group)
     const int st_slot = A.ck_pair_slot[has_slot ? qb + tid : 0];
@@ -138,6 +140,7 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
     const double floor_now = A.state->floor;
     for (int i = tid; i < npts * 9; i += CHUNK_OBS) sP[i] = 0.0;
     for (int i = tid; i < ncam * 33; i += CHUNK_OBS) sC[i] = 0.0;
+    if (tid < ncam) sCam[tid] = st_cam;
     if (has_pg) sPg[tid] = st_pg;
     if (has_slot) sSlot[tid] = st_slot;
     __syncthreads();
@@ -250,11 +253,15 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
     }
     BA_STAMP(5);
     {
-        const double cs = block_sum256(cost_loc, sRed);
-        const double gm = block_max256(gmax_loc, sRed);
-        if (tid == 0) { A.ck_cost[ck] = cs; A.ck_gmax[ck] = gm; }
+        // chunk cost and max |g_p|: DPP wave reductions, the four wave results cross the barrier that 2b needs anyway
+        const double cs = wave_sum_dpp(cost_loc), gm = wave_max_dpp(gmax_loc);
+        if ((tid & 63) == 0) { sRed[tid >> 6] = cs; sRed[4 + (tid >> 6)] = gm; }
     }
     __syncthreads();
+    if (tid == 0) {
+        A.ck_cost[ck] = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
+        A.ck_gmax[ck] = fmax(fmax(sRed[4], sRed[5]), fmax(sRed[6], sRed[7]));
+    }
 
     BA_STAMP(6);
     // ---- phase 2b: T = W L^-T into LDS (overwrites the phase-1 staging) ---------------------------
@@ -363,7 +370,7 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
     // ---- phase 4: one flush per chunk (fp64 atomics to HBM) ------------------------------------------
     for (int i = tid; i < ncam * 33; i += CHUNK_OBS) {
         const int l = i / 33, k = i - l * 33;
-        const size_t f = (size_t)A.ck_cam_list[cb + l];
+        const size_t f = (size_t)sCam[l];
         const double v = sC[i];
         if (k < 21) atomicAdd(&A.U[f * 21 + k], v);
         else if (k < 27) atomicAdd(&A.gc[f * 6 + (k - 21)], v);
