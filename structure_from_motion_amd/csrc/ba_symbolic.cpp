@@ -286,6 +286,17 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
         s.hv_pair.push_back((int64_t)s.hv_keys.size());
     }
     tick("heavy points");
+    if (tm_on) {
+        long long groups = 0, pairs = 0;
+        for (size_t c = 0; c + 1 < s.ck_pair.size(); ++c) {
+            const int np_ = s.ck_pair[c + 1] - s.ck_pair[c];
+            groups += s.ck_pgrp[s.ck_pair[c] + c + np_];
+            pairs += np_;
+        }
+        fprintf(stderr, "[symbolic] chunks %zu, pairs %lld, groups %lld, real entries %lld (fill %.1f %% of the groups, %.1f %% of the padded rounds)\n",
+                s.ck_obs.size() - 1, pairs, groups, (long long)s.n_pair_real, 100.0 * s.n_pair_real / (groups * (double)PAIR_RUN),
+                100.0 * s.n_pair_real / (double)(s.pair_entries.size() - (size_t)(CHUNK_OBS / 2) * PAIR_RUN));
+    }
     // (the build kernel prefetches one round of entries unconditionally: readable padding behind the last chunk)
     s.pair_entries.resize(s.pair_entries.size() + (size_t)(CHUNK_OBS / 2) * PAIR_RUN, PAIR_NULL);
     // slots are resolved by finalize_pattern (the pattern may be a union over ranks)
