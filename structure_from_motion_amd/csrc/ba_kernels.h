@@ -87,6 +87,9 @@ __device__ __forceinline__ double block_max256(double v, double *scratch) {
     do {                                                                          \
         if (STAMP && tid == 0) A.stamps[(size_t)ck * 12 + (i)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
+constexpr int U_REPLICAS = 4;
+constexpr int U_REP_STRIDE = CHUNK_CAMS * 27 + 20;  // doubles; 776 = 16 banks (of 4 bytes) past a multiple of 64
+static_assert(U_REPLICAS * U_REP_STRIDE <= CHUNK_OBS * 18, "the replicas live in the T buffer");
 template <bool STAMP>
 __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_build(const BuildArgs A) {
     __shared__ __attribute__((aligned(16))) double sT[CHUNK_OBS * 18];   // T = W L^-T per observation (6x3)
@@ -140,6 +143,11 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
     const double floor_now = A.state->floor;
     for (int i = tid; i < npts * 9; i += CHUNK_OBS) sP[i] = 0.0;
     for (int i = tid; i < ncam * 33; i += CHUNK_OBS) sC[i] = 0.0;
+    // four replicas of the cameras' U / g_c tiles in the T buffer, which is idle until phase 2b (see phase 1)
+    for (int i = tid; i < ncam * 27; i += CHUNK_OBS) {
+#pragma unroll
+        for (int r = 0; r < U_REPLICAS; ++r) sT[r * U_REP_STRIDE + i] = 0.0;
+    }
     if (tid < ncam) sCam[tid] = st_cam;
     if (has_pg) sPg[tid] = st_pg;
     if (has_slot) sSlot[tid] = st_slot;
@@ -186,7 +194,10 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
                 // per-camera U (21) and g_c (6): LDS atomics into the camera's tile.  (A gather through a camera-sorted
                 // observation list, without atomics, won at two workgroups per CU; at three the VALU is the scarcer
                 // unit and the plain atomics are faster.)
-                double *cp = &sC[lc * 33];
+                // Same-address fp64 LDS atomics serialise (1.5 lane-ops per clock for this pattern against 8.6 for
+                // distinct addresses, tools/lds_bench.hip): the lanes of one camera are spread over four bank-shifted
+                // replicas of its tile by their point index (4.3 lane-ops per clock); summed after the barrier.
+                double *cp = &sT[(lp & (U_REPLICAS - 1)) * U_REP_STRIDE + lc * 27];
 #pragma unroll
                 for (int i = 0; i < 6; ++i) {
 #pragma unroll
@@ -216,6 +227,14 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
     __syncthreads();
 
     BA_STAMP(3);
+    // camera tiles = sum of their replicas (highest lanes first: the low lanes have a point each in phase 2a)
+    for (int item = CHUNK_OBS - 1 - tid; item < ncam * 27; item += CHUNK_OBS) {
+        const int l = item / 27;
+        double v = 0.0;
+#pragma unroll
+        for (int r = 0; r < U_REPLICAS; ++r) v += sT[r * U_REP_STRIDE + item];
+        sC[l * 33 + (item - l * 27)] = v;
+    }
     BA_STAMP(4);
     // ---- phase 2a: one point per lane: damp, 3x3 Cholesky, inverse factor in registers ------
     double gmax_loc = 0.0;

@@ -16,8 +16,9 @@ __global__ __launch_bounds__(256) void k(double *out, int iters) {
     else if (MODE == 2) a = (tid % 36) + 36 * ((tid * 7 / 36) % 60);  // two 36-lane groups, random slots
     else if (MODE == 3) a = (tid / 6) % 10 * 33;  // ~6-way same address (camera tile)
     else if (MODE == 6) a = (tid % 5 + (tid / 5) / 8 % 3) * 33;            // k_build U pattern: point-major lanes, 7 camera tiles
-    else if (MODE == 7) a = (tid % 5 + (tid / 5) / 8 % 3) * 33 + ((tid / 5) & 1) * 1024;  // same, two replicas by point parity
-    else if (MODE == 8) a = (tid % 5 + (tid / 5) / 8 % 3) * 33 + ((tid / 5) & 3) * 1024;  // four replicas
+    else if (MODE == 7) a = (tid % 5 + (tid / 5) / 8 % 3) * 33 + ((tid / 5) & 1) * (1024 + 8);  // same, two replicas by point parity (bank-shifted)
+    else if (MODE == 8) a = (tid % 5 + (tid / 5) / 8 % 3) * 33 + ((tid / 5) & 3) * (1024 + 8);  // four replicas
+    else if (MODE == 10) a = (tid % 5 + (tid / 5) / 8 % 3) * 33 + ((tid / 5) & 7) * (512 + 4);  // eight replicas
     else if (MODE == 9) a = (tid / 5) * 9;                                // k_build P pattern: 5 adjacent lanes per point
     else a = tid * 18;                      // MODE 4/5: reads at stride 144 B
     for (int it = 0; it < iters; ++it) {
@@ -64,6 +65,7 @@ int main() {
     run<6>("ds_add_f64 U pattern (7 tiles, strided lanes)", d, 2000, 8);
     run<7>("ds_add_f64 U pattern, 2 replicas", d, 2000, 8);
     run<8>("ds_add_f64 U pattern, 4 replicas", d, 2000, 8);
+    run<10>("ds_add_f64 U pattern, 8 replicas", d, 2000, 8);
     run<9>("ds_add_f64 P pattern (5 adjacent lanes)", d, 2000, 8);
     run<4>("ds_read 18 doubles/lane stride 144B", d, 2000, 18);
     run<5>("ds_read_b64 consecutive", d, 2000, 18);
