@@ -89,7 +89,8 @@ __device__ __forceinline__ double block_max256(double v, double *scratch) {
     } while (0)
 constexpr int U_REPLICAS = 4;
 constexpr int U_REP_STRIDE = CHUNK_CAMS * 27 + 20;  // doubles; 776 = 16 banks (of 4 bytes) past a multiple of 64
-static_assert(U_REPLICAS * U_REP_STRIDE <= CHUNK_OBS * 18, "the replicas live in the T buffer");
+constexpr int P_REP_BASE = U_REPLICAS * U_REP_STRIDE + 6;  // second replica of the per-point sums, behind the camera replicas
+static_assert(P_REP_BASE + CHUNK_PTS * 9 <= CHUNK_OBS * 18, "the replicas live in the T buffer");
 template <bool STAMP>
 __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_build(const BuildArgs A) {
     __shared__ __attribute__((aligned(16))) double sT[CHUNK_OBS * 18];   // T = W L^-T per observation (6x3)
@@ -148,6 +149,7 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
 #pragma unroll
         for (int r = 0; r < U_REPLICAS; ++r) sT[r * U_REP_STRIDE + i] = 0.0;
     }
+    for (int i = tid; i < npts * 9; i += CHUNK_OBS) sT[P_REP_BASE + i] = 0.0;  // second replica of the point sums
     if (tid < ncam) sCam[tid] = st_cam;
     if (has_pg) sPg[tid] = st_pg;
     if (has_slot) sSlot[tid] = st_slot;
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
     // per-point sums V (6), g_p (3): LDS atomics (same reasoning; the segmented wave reduction they replace cost
     // more VALU and shuffle time than the atomics cost LDS time)
     if (act) {
-        double *vp = &sP[lp * 9];
+        double *vp = (tid & 1) ? &sT[P_REP_BASE + lp * 9] : &sP[lp * 9];  // neighbouring lanes: alternate replicas
 #pragma unroll
         for (int k = 0; k < 9; ++k) atomicAdd(&vp[k], vs[k]);
     }
@@ -240,8 +242,10 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
     double gmax_loc = 0.0;
     if (tid < npts) {
         double *vp = &sP[tid * 9];
-        const double v00 = vp[0], v01 = vp[1], v02 = vp[2], v11 = vp[3], v12 = vp[4], v22 = vp[5];
-        const double g0 = vp[6], g1 = vp[7], g2 = vp[8];
+        const double *rp = &sT[P_REP_BASE + tid * 9];
+        const double v00 = vp[0] + rp[0], v01 = vp[1] + rp[1], v02 = vp[2] + rp[2], v11 = vp[3] + rp[3], v12 = vp[4] + rp[4],
+                     v22 = vp[5] + rp[5];
+        const double g0 = vp[6] + rp[6], g1 = vp[7] + rp[7], g2 = vp[8] + rp[8];
         gmax_loc = fmax(fabs(g0), fmax(fabs(g1), fabs(g2)));
         if (A.dbg_v) {
             double *dv = &A.dbg_v[(size_t)(pb + tid) * 6];
