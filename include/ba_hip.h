@@ -149,6 +149,13 @@ void ba_destroy(BaHandle *h);
 int ba_get_pattern(BaHandle *h, int32_t *out_pairs, int64_t capacity, int64_t *n_pairs);
 int ba_set_pattern(BaHandle *h, const int32_t *pairs, int64_t n_pairs);
 int ba_set_collective(BaHandle *h, BaCollectiveFn fn, void *user, int32_t rank, int32_t world);
+/* How the callback is ordered against the library's work.  0 (default): the library synchronises its stream before
+ * the call, and the callback returns when the collective is complete.  1 (stream-ordered): no host synchronisation;
+ * the callback ENQUEUES the collective on the handle's HIP stream (ba_get_stream) -- after the work already queued
+ * there -- and may return at once; the library queues its next kernels behind it.  (No reference counterpart: the
+ * reference is single-process.) */
+int ba_set_collective_mode(BaHandle *h, int32_t stream_ordered);
+int ba_get_stream(BaHandle *h, void **stream); /* the hipStream_t every kernel of this handle runs on */
 /* One residual + Jacobian + Schur-complement pass at the current state with damping lambda:
  * (x, lambda) -> cost, reduced camera system S, reduced gradient.  The benchmark unit. */
 int ba_build(BaHandle *h, double lambda);

@@ -24,7 +24,7 @@ EXPORTED = [
     "ba_eval_jacobian_blocks", "ba_eval_reprojection_errors", "ba_analyze", "ba_create", "ba_destroy",
     "ba_get_pattern", "ba_set_pattern", "ba_set_collective", "ba_build", "ba_build_bench", "ba_run",
     "ba_get_state", "ba_get_cost", "ba_get_reduced_system", "ba_get_reduced_blocks", "ba_synchronize",
-    "ba_set_values",
+    "ba_set_values", "ba_set_collective_mode", "ba_get_stream",
 ]
 
 
@@ -111,6 +111,8 @@ def load():
     lib.ba_get_reduced_system.argtypes = [C.c_void_p] + [C.c_void_p] * 6
     lib.ba_get_reduced_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, P(C.c_int64)]
     lib.ba_synchronize.argtypes = [C.c_void_p]
+    lib.ba_set_collective_mode.argtypes = [C.c_void_p, C.c_int32]
+    lib.ba_get_stream.argtypes = [C.c_void_p, P(C.c_void_p)]
     lib.ba_set_values.argtypes = [C.c_void_p, P(BaProblem), P(BaOptions)]
     for name in EXPORTED:
         if name not in ("ba_last_error", "ba_default_options", "ba_create", "ba_destroy"):
@@ -290,8 +292,16 @@ class Handle:
         pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
         check(self._lib.ba_set_pattern(self.h, pairs.ctypes.data, len(pairs)))
 
-    def set_collective(self, fn, rank, world):
-        """fn(dev_ptr:int, count:int, op:int) -> int (0 = ok)."""
+    def stream(self):
+        """The hipStream_t (as an integer) every kernel of this handle runs on."""
+        p = C.c_void_p()
+        check(self._lib.ba_get_stream(self.h, C.byref(p)))
+        return p.value or 0
+
+    def set_collective(self, fn, rank, world, stream_ordered=False):
+        """fn(dev_ptr:int, count:int, op:int) -> int (0 = ok).  ``stream_ordered``: fn enqueues the collective on
+        ``self.stream()`` and the library does not synchronise around the call (``ba_set_collective_mode``)."""
+        check(self._lib.ba_set_collective_mode(self.h, 1 if stream_ordered else 0))
         def tramp(ptr, count, op, _user):
             try:
                 return int(fn(ptr, count, op) or 0)

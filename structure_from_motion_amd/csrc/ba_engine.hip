@@ -174,6 +174,7 @@ struct BaHandle {
     BaCollectiveFn coll = nullptr;
     void *coll_user = nullptr;
     int rank = 0, world = 1;
+    bool coll_stream_ordered = false;  // the callback enqueues on `stream`; no host synchronisation around it
     // bookkeeping
     int total_pcg = 0;
     double initial_cost = NAN;
@@ -220,8 +221,8 @@ int upload_pattern(BaHandle *h) {
 }
 
 int call_coll(BaHandle *h, void *ptr, int64_t n, int op) {
-    if (!h->coll || h->world <= 1) return BA_OK;
-    HIPCHK(hipStreamSynchronize(h->stream));
+    if (!h->coll) return BA_OK;
+    if (!h->coll_stream_ordered) HIPCHK(hipStreamSynchronize(h->stream));
     if (h->opt.verbose >= 3) { fprintf(stderr, "[ba_hip r%d] collective op %d n %lld\n", h->rank, op, (long long)n); fflush(stderr); }
     if (h->coll(ptr, n, op, h->coll_user) != 0) return fail(BA_ERR_COMM, "collective callback failed");
     if (h->opt.verbose >= 3) { fprintf(stderr, "[ba_hip r%d] collective done\n", h->rank); fflush(stderr); }
@@ -283,7 +284,7 @@ int do_build(BaHandle *h, bool timed) {
     if (timed) HIPCHK(hipEventRecord(h->ev1, st));
     if (h->n_heavy > 0) hipLaunchKernelGGL(k_build_heavy, dim3(h->n_heavy), dim3(256), 0, st, build_args(h), heavy_args(h));
     hipLaunchKernelGGL(k_chunk_totals, dim3(1), dim3(1024), 0, st, h->n_chunks + h->n_heavy, h->ck_cost.p, h->ck_gmax.p, h->sums, h->gm2.p);
-    if (h->world > 1) {
+    if (h->coll) {
         // ONE collective per build: the maximum over ranks of the point-gradient norm rides in the sum buffer,
         // each rank's value in its own slot of the tail (zero elsewhere), and is maximised locally afterwards
         hipLaunchKernelGGL(k_copy_scalar, dim3(1), dim3(1), 0, st, h->gm2.p, h->red.p + nred + h->rank);
@@ -403,7 +404,7 @@ int do_step(BaHandle *h) {
     }
     if (!solved && (e = do_pcg(h, &pcg_it))) return e;
     h->total_pcg += pcg_it;
-    if (h->world > 1 && s.n_free > 0 && (e = call_coll(h, h->px.p, (int64_t)s.n_free * 6, BA_BROADCAST0))) return e;
+    if (h->coll && s.n_free > 0 && (e = call_coll(h, h->px.p, (int64_t)s.n_free * 6, BA_BROADCAST0))) return e;
     const int cur = h->cur, tr = cur ^ 1;
     hipLaunchKernelGGL(k_cam_update, dim3((s.n_cams + 63) / 64), dim3(64), 0, st, s.n_cams, h->cam_free.p, h->pose[cur].p,
                        h->intr.p, h->px.p, h->pose[tr].p, h->aux[tr].p, h->cam_part.p);
@@ -429,7 +430,7 @@ int do_step(BaHandle *h) {
     // |x|^2 of this rank's unobserved points joins the partial sums BEFORE the all-reduce so that
     // every rank takes the same decision
     hipLaunchKernelGGL(k_add_scalar, dim3(1), dim3(1), 0, st, h->step_sums.p + 3, h->x2_const);
-    if (h->world > 1 && (e = call_coll(h, h->step_sums.p, 4, BA_REDUCE_SUM))) return e;
+    if (h->coll && (e = call_coll(h, h->step_sums.p, 4, BA_REDUCE_SUM))) return e;
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(1), 0, st, h->state.p, h->step_sums.p, h->cam_sums.p, 0.0,
                        h->opt.ftol, h->opt.xtol);
     HIPCHK(hipGetLastError());
@@ -740,6 +741,18 @@ int ba_set_collective(BaHandle *h, BaCollectiveFn fn, void *user, int32_t rank, 
     if (world > BA_MAX_WORLD || rank < 0 || (world >= 1 && rank >= world)) return fail(BA_ERR_INVALID, "rank %d of %d (at most %d ranks)", rank, world, BA_MAX_WORLD);
     h->rank = rank;
     h->world = world < 1 ? 1 : world;
+    return BA_OK;
+}
+
+int ba_set_collective_mode(BaHandle *h, int32_t stream_ordered) {
+    if (!h) return fail(BA_ERR_INVALID, "null handle");
+    h->coll_stream_ordered = stream_ordered != 0;
+    return BA_OK;
+}
+
+int ba_get_stream(BaHandle *h, void **stream) {
+    if (!h || !stream) return fail(BA_ERR_INVALID, "null argument");
+    *stream = (void *)h->stream;
     return BA_OK;
 }
 

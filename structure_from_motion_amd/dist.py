@@ -28,18 +28,28 @@ class _DevArray:
                                          "version": 2, "strides": None}
 
 
-def make_collective(group=None):
-    """Collective callback for ``Handle.set_collective`` backed by torch.distributed."""
+def make_collective(group=None, stream=None):
+    """Collective callback for ``Handle.set_collective`` backed by torch.distributed.
+
+    ``stream`` (a hipStream_t as an integer, ``Handle.stream()``), nccl backend only: the collectives are enqueued in
+    stream order on that stream -- torch orders RCCL's own stream behind it and it behind RCCL's -- and the callback
+    returns without waiting, so a build pass or an LM step has no host round trip around its all-reduce
+    (``set_collective(..., stream_ordered=True)``).  Without it the callback blocks until the collective is done."""
     import torch
     import torch.distributed as dist
 
     host_staged = dist.get_backend(group) != "nccl"  # e.g. gloo in the single-GPU tests
     views = {}  # (pointer, count) -> tensor aliasing the library's buffer (the buffers live as long as the handle)
+    ext = torch.cuda.ExternalStream(stream) if (stream and not host_staged) else None
 
     def coll(ptr, count, op):
         dev = views.get((ptr, count))
         if dev is None:
             dev = views[(ptr, count)] = torch.as_tensor(_DevArray(ptr, count), device="cuda")
+        if ext is not None:
+            with torch.cuda.stream(ext):
+                _run(dev, op)
+            return 0
         t = dev.cpu() if host_staged else dev
         _run(t, op)
         if host_staged:
@@ -54,6 +64,7 @@ def make_collective(group=None):
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         else:
             dist.broadcast(t, src=0, group=group)
+    coll.stream_ordered = ext is not None
     return coll
 
 
@@ -82,15 +93,18 @@ def shard_points(prob, rank, world):
     return shard, np.arange(lo, hi)
 
 
-def create_sharded_handle(shard, rank, world, group=None, **opts):
-    """Handle for this rank's shard with the shared pattern and the RCCL collectives installed."""
+def create_sharded_handle(shard, rank, world, group=None, stream_ordered=True, force_collectives=False, **opts):
+    """Handle for this rank's shard with the shared pattern and the RCCL collectives installed (stream-ordered on
+    the nccl backend unless ``stream_ordered=False``).  ``force_collectives`` installs them for a world of one as
+    well (tests: the whole sharded path on a single GPU)."""
     import torch.distributed as dist
     h = _capi.Handle(_capi.Arrays.from_dict(shard), **opts)
-    if world > 1:
+    if world > 1 or force_collectives:
         def gather(obj):
             out = [None] * world
             dist.all_gather_object(out, obj, group=group)
             return out
         h.set_pattern(union_pattern(h.pattern(), gather))
-        h.set_collective(make_collective(group), rank, world)
+        coll = make_collective(group, h.stream() if stream_ordered else None)
+        h.set_collective(coll, rank, world, stream_ordered=coll.stream_ordered)
     return h

@@ -86,3 +86,31 @@ def engine_sharded_solve(rank, world, port, out_dir):
              iters=s["iterations"])
     h.close()
     dist.destroy_process_group()
+
+
+def engine_nccl_single_rank(rank, world, port, out_dir):
+    """GPU: RCCL itself (backend nccl, a world of one rank) under the sharded code path with the collectives forced
+    on -- the aliasing of the library's buffers by torch tensors and both orderings of the callback (blocking, and
+    stream-ordered on the handle's stream) are exactly what an 8-GPU run uses; only the peers are missing."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from structure_from_motion_amd import synthetic
+    from structure_from_motion_amd import dist as badist
+    p = synthetic.make_ring(16, 600, seed=8, mean_track=4.0, outlier_frac=0.02)
+    sh, pidx = badist.shard_points(p, 0, 1)
+    out = {}
+    for name, ordered in (("blocking", False), ("ordered", True)):
+        h = badist.create_sharded_handle(sh, 0, 1, stream_ordered=ordered, force_collectives=True, loss="huber",
+                                         f_scale=1.0, max_iter=80, device=0)
+        ms_pass, _ = h.build_bench(1e-4, warmup=2, reps=20)          # back-to-back passes, collectives in between
+        s = h.run()
+        cp, pts = h.state()
+        out[name + "_cp"], out[name + "_pts"] = cp, pts
+        out[name + "_cost"], out[name + "_status"], out[name + "_ms"] = s["final_cost"], s["status"], ms_pass
+        h.close()
+    np.savez(os.path.join(out_dir, "nccl1.npz"), **out)
+    dist.destroy_process_group()
