@@ -125,14 +125,12 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
     const long long peb = A.ck_pe[ck];
     const int rounds = (int)((A.ck_pe[ck + 1] - peb) / ((CHUNK_OBS / 2) * PAIR_RUN));
     const int half = tid & 1;
-    unsigned ents[PAIR_RUN];
+    unsigned ents[PAIR_RUN / 2];  // lane `half` of lane pair g takes entries 4 half .. 4 half + 3 of group g
     {
         // (a chunk without pair entries reads the next chunk's first words, or the padding at the end of the array)
-        const uint4 *ep = reinterpret_cast<const uint4 *>(A.pair_entries + peb) + (size_t)(tid >> 1) * 2;
-        const uint4 e0 = ep[0], e1 = ep[1];
+        const uint4 e0 = reinterpret_cast<const uint4 *>(A.pair_entries + peb)[tid];
         const bool any = rounds > 0;
         ents[0] = any ? e0.x : PAIR_NULL; ents[1] = any ? e0.y : PAIR_NULL; ents[2] = any ? e0.z : PAIR_NULL; ents[3] = any ? e0.w : PAIR_NULL;
-        ents[4] = any ? e1.x : PAIR_NULL; ents[5] = any ? e1.y : PAIR_NULL; ents[6] = any ? e1.z : PAIR_NULL; ents[7] = any ? e1.w : PAIR_NULL;
     }
     const int cam = A.o_cam[oo];
     const int p = A.o_pt[oo];
@@ -314,78 +312,85 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
 
     // ---- phase 3: Schur-complement blocks and reduced gradient ----------------------------------
     // The chunk's (observation i, observation j) entries come in groups of PAIR_RUN entries of ONE camera pair
-    // (ba_symbolic.cpp).  Lane pair g reduces group g: each lane keeps one half (3 of 6 rows) of the partial
-    // block -sum T_i T_j^T in registers.  No LDS atomics: once every lane is done with T, the partial blocks
-    // are parked in sT (exactly 36 doubles per lane pair) and phase 4 sums the groups of each pair.
-    // Self entries (i == j) also carry -T_i u_p of the reduced gradient (camera tile, LDS atomics: few).
-    // LDS reads of entry k+1 are issued before the arithmetic of entry k.
+    // (ba_symbolic.cpp).  Lane pair g reduces group g: each lane takes FOUR of the eight entries and forms their whole
+    // 6x6 products -sum T_i T_j^T in registers, so every T row of an entry is read from LDS exactly once (39 doubles per
+    // entry; splitting the block by rows instead read T_j twice: 60).  The odd lane numbers its rows from 3, so that
+    // accumulators 0..17 of both lanes are the rows they keep: one DPP exchange of the other 18 sums the two lanes.
+    // No LDS atomics: once every lane is done with T, the partial blocks are parked in sT (exactly 36 doubles per lane
+    // pair) and phase 4 sums the groups of each pair.  Self entries (i == j) also carry -T_i u_p of the reduced
+    // gradient (camera tile, LDS atomics: few).  Groups beyond the first CHUNK_OBS / 2 of a chunk (rare: long tracks)
+    // are done first and go to HBM straight from the registers.
     {
-        auto fetch = [&](unsigned ent, double *a9, double *b18, double *u3) {
-            if (ent == PAIR_NULL) ent = 0u;  // a null entry reads observation 0: harmless
-            const int oi = ent & 255u, oj = (ent >> 8) & 255u;
-            const double *ti = &sT[oi * 18 + half * 9], *tj = &sT[oj * 18], *uu = &sP[(int)sLp[oi] * 9 + 6];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) a9[k] = ti[k];
-#pragma unroll
-            for (int k = 0; k < 18; ++k) b18[k] = tj[k];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) u3[k] = uu[k];
-        };
-        double acc[18];
-        for (int round = 0; round < (rounds > 0 ? rounds : 1); ++round) {
+        double acc[36];
+        const int rot = half * 9;  // the odd lane reads rows 3..5 of T_i first
+        for (int round = (rounds > 0 ? rounds : 1) - 1; round >= 0; --round) {
+            unsigned en[PAIR_RUN / 2];
             if (round > 0) {
-                const uint4 *ep = reinterpret_cast<const uint4 *>(A.pair_entries + peb) +
-                                  ((size_t)round * (CHUNK_OBS / 2) + (tid >> 1)) * 2;
-                const uint4 e0 = ep[0], e1 = ep[1];
-                ents[0] = e0.x; ents[1] = e0.y; ents[2] = e0.z; ents[3] = e0.w;
-                ents[4] = e1.x; ents[5] = e1.y; ents[6] = e1.z; ents[7] = e1.w;
+                const uint4 e0 = reinterpret_cast<const uint4 *>(A.pair_entries + peb)[(size_t)round * CHUNK_OBS + tid];
+                en[0] = e0.x; en[1] = e0.y; en[2] = e0.z; en[3] = e0.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < PAIR_RUN / 2; ++e) en[e] = ents[e];
             }
-            double gacc[3], ta[1][9], tb[1][18], tu[1][3];
+            double gacc[6];
             int self_lc = -1;
 #pragma unroll
-            for (int k = 0; k < 18; ++k) acc[k] = 0.0;
+            for (int k = 0; k < 36; ++k) acc[k] = 0.0;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) gacc[k] = 0.0;
+            for (int k = 0; k < 6; ++k) gacc[k] = 0.0;
 #pragma unroll
-            for (int e = 0; e < PAIR_RUN; ++e) {
-                fetch(ents[e], ta[0], tb[0], tu[0]);
-                const unsigned ent = ents[e];
-                if (ent != PAIR_NULL) {
-                    const double *a9 = ta[0], *b18 = tb[0], *u3 = tu[0];
+            for (int e = 0; e < PAIR_RUN / 2; ++e) {
+                const unsigned ent = en[e];
+                const unsigned ec = ent == PAIR_NULL ? 0u : ent;  // a null entry reads observation 0: harmless
+                const int oi = ec & 255u, oj = (ec >> 8) & 255u;
+                const double *ti = &sT[oi * 18], *tj = &sT[oj * 18], *uu = &sP[(int)sLp[oi] * 9 + 6];
+                double ta[9], tb[18], tu[3];
+                const bool real = ent != PAIR_NULL, self = real && oi == oj;
+                if (self) self_lc = sLc[oi];
 #pragma unroll
-                    for (int rr = 0; rr < 3; ++rr)
+                for (int k = 0; k < 18; ++k) tb[k] = tj[k];
 #pragma unroll
-                        for (int c = 0; c < 6; ++c)
-                            acc[rr * 6 + c] -= a9[rr * 3] * b18[c * 3] + a9[rr * 3 + 1] * b18[c * 3 + 1] + a9[rr * 3 + 2] * b18[c * 3 + 2];
-                    const int oi = ent & 255u, oj = (ent >> 8) & 255u;
-                    if (oi == oj) {
-                        self_lc = sLc[oi];
+                for (int k = 0; k < 3; ++k) tu[k] = uu[k];
 #pragma unroll
-                        for (int rr = 0; rr < 3; ++rr) gacc[rr] -= a9[rr * 3] * u3[0] + a9[rr * 3 + 1] * u3[1] + a9[rr * 3 + 2] * u3[2];
+                for (int hh = 0; hh < 2; ++hh) {  // three row slots at a time: nine doubles of T_i live, not eighteen
+                    const double *tih = ti + (hh == 0 ? rot : 9 - rot);
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) ta[k] = tih[k];
+                    if (real) {
+#pragma unroll
+                        for (int rr = 0; rr < 3; ++rr) {
+#pragma unroll
+                            for (int c = 0; c < 6; ++c)
+                                acc[(hh * 3 + rr) * 6 + c] -= ta[rr * 3] * tb[c * 3] + ta[rr * 3 + 1] * tb[c * 3 + 1] + ta[rr * 3 + 2] * tb[c * 3 + 2];
+                            if (self) gacc[hh * 3 + rr] -= ta[rr * 3] * tu[0] + ta[rr * 3 + 1] * tu[1] + ta[rr * 3 + 2] * tu[2];
+                        }
                     }
                 }
             }
             if (self_lc >= 0 && self_lc < CHUNK_CAMS) {
-                double *d = &sC[self_lc * 33 + 27 + half * 3];
+                double *d = &sC[self_lc * 33 + 27];
 #pragma unroll
-                for (int rr = 0; rr < 3; ++rr) atomicAdd(&d[rr], gacc[rr]);
+                for (int rr = 0; rr < 3; ++rr) {  // slots 0..2 are rows 3 half .., slots 3..5 the other three
+                    atomicAdd(&d[half * 3 + rr], gacc[rr]);
+                    atomicAdd(&d[3 - half * 3 + rr], gacc[3 + rr]);
+                }
             }
-            if (round > 0 && ents[0] != PAIR_NULL) {
-                // groups beyond the first CHUNK_OBS / 2 (rare): straight to HBM
-                double *d = &A.S[(size_t)A.ck_pair_slot[qb + (int)(ents[0] >> 16)] * 36 + half * 18];
+            if (round > 0 && en[0] != PAIR_NULL) {
+                double *d = &A.S[(size_t)A.ck_pair_slot[qb + (int)(en[0] >> 16)] * 36];
 #pragma unroll
-                for (int k = 0; k < 18; ++k) atomicAdd(&d[k], acc[k]);
-            }
-            if (round == 0) {
-                // the first round's partial block waits in registers until no lane needs T any more
-#pragma unroll
-                for (int k = 0; k < 18; ++k) W[k] = acc[k];  // (W is dead since phase 2b: reuse its registers)
+                for (int k = 0; k < 18; ++k) {
+                    atomicAdd(&d[half * 18 + k], acc[k]);
+                    atomicAdd(&d[18 - half * 18 + k], acc[18 + k]);
+                }
             }
         }
+        // round 0 is still in the registers: add the partner lane's sums of the rows this lane keeps
+#pragma unroll
+        for (int k = 0; k < 18; ++k) acc[k] += dpp_f64<0xB1>(acc[18 + k]);
         __syncthreads();  // every lane is done reading T
         double *park = &sT[(tid >> 1) * 36 + half * 18];
 #pragma unroll
-        for (int k = 0; k < 18; ++k) park[k] = W[k];
+        for (int k = 0; k < 18; ++k) park[k] = acc[k];
     }
     __syncthreads();
 
