@@ -344,7 +344,7 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
                 const unsigned ec = ent == PAIR_NULL ? 0u : ent;  // a null entry reads observation 0: harmless
                 const int oi = ec & 255u, oj = (ec >> 8) & 255u;
                 const double *ti = &sT[oi * 18], *tj = &sT[oj * 18], *uu = &sP[(int)sLp[oi] * 9 + 6];
-                double ta[9], tb[18], tu[3];
+                double tb[18], tu[3];
                 const bool real = ent != PAIR_NULL, self = real && oi == oj;
                 if (self) self_lc = sLc[oi];
 #pragma unroll
@@ -352,17 +352,22 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
 #pragma unroll
                 for (int k = 0; k < 3; ++k) tu[k] = uu[k];
 #pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {  // three row slots at a time: nine doubles of T_i live, not eighteen
-                    const double *tih = ti + (hh == 0 ? rot : 9 - rot);
+                for (int hh = 0; hh < 3; ++hh) {  // two row slots at a time: six doubles of T_i live, not eighteen
+                    double ta[6];
 #pragma unroll
-                    for (int k = 0; k < 9; ++k) ta[k] = tih[k];
+                    for (int q = 0; q < 2; ++q) {
+                        const int s3 = (hh * 2 + q) * 3;                                  // slot s holds row (s + 3 half) mod 6
+                        const double *tis = ti + (s3 + rot >= 18 ? s3 + rot - 18 : s3 + rot);
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) ta[q * 3 + k] = tis[k];
+                    }
                     if (real) {
 #pragma unroll
-                        for (int rr = 0; rr < 3; ++rr) {
+                        for (int rr = 0; rr < 2; ++rr) {
 #pragma unroll
                             for (int c = 0; c < 6; ++c)
-                                acc[(hh * 3 + rr) * 6 + c] -= ta[rr * 3] * tb[c * 3] + ta[rr * 3 + 1] * tb[c * 3 + 1] + ta[rr * 3 + 2] * tb[c * 3 + 2];
-                            if (self) gacc[hh * 3 + rr] -= ta[rr * 3] * tu[0] + ta[rr * 3 + 1] * tu[1] + ta[rr * 3 + 2] * tu[2];
+                                acc[(hh * 2 + rr) * 6 + c] -= ta[rr * 3] * tb[c * 3] + ta[rr * 3 + 1] * tb[c * 3 + 1] + ta[rr * 3 + 2] * tb[c * 3 + 2];
+                            if (self) gacc[hh * 2 + rr] -= ta[rr * 3] * tu[0] + ta[rr * 3 + 1] * tu[1] + ta[rr * 3 + 2] * tu[2];
                         }
                     }
                 }
