@@ -114,6 +114,31 @@ def test_session_path_equals_module_functions(gpu):
     sess.close()
 
 
+def test_incremental_driver_pattern(gpu):
+    """The reference driver's loop (Reconstruction.py:253-255): inter_ba after every new image on a growing set of
+    registered images, results fed back into the next call.  The session (array marshalling, cached keypoints, kept
+    handle) and the module functions must walk the same states."""
+    from structure_from_motion_amd.session import BASession
+    g = load_golden("marshalling")
+    ids, image_data, pts = _image_data_from_golden(g)
+    d1, d2 = copy.deepcopy(image_data), copy.deepcopy(image_data)
+    p1, p2 = pts, pts
+    sess = BASession()
+    ran = 0
+    for n in range(3, len(ids) + 1):
+        for rep in range(2):                 # the second call sees the same structure: handle re-used, values re-uploaded
+            p1, d1, ok1 = BA.inter_ba(d1, p1, ids[:n], ba_interval=1, verbose=False)
+            p2, d2, ok2 = sess.inter_ba(d2, p2, ids[:n], ba_interval=1, verbose=False)
+            assert ok1 == ok2
+            ran += bool(ok2)
+            np.testing.assert_allclose(np.array(p2)[:, :3], np.array(p1)[:, :3], rtol=0, atol=1e-5)
+            for cid in ids[:n]:
+                np.testing.assert_allclose(d2[cid][0], d1[cid][0], rtol=0, atol=1e-6)
+                np.testing.assert_allclose(d2[cid][1], d1[cid][1], rtol=0, atol=1e-5)
+    assert ran >= 2 and sess.handle_reuses >= ran // 2
+    sess.close()
+
+
 def test_opt_in_point_culling(gpu):
     """SURVEY 8(f) f4 (opt-in, not reference behaviour): a grossly wrong observation un-references its point."""
     from structure_from_motion_amd.session import BASession
