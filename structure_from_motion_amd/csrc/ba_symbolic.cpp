@@ -161,8 +161,18 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
             for (int l = 0; l < cur_pairs; ++l) {
                 const size_t j = i + pair_cnt[l];
                 s.ck_pgrp.push_back(n_groups);
-                for (size_t k = i; k < j; k += PAIR_RUN, ++n_groups)
-                    for (size_t u = 0; u < (size_t)PAIR_RUN; ++u) s.pair_entries.push_back(k + u < j ? sorted[k + u] : PAIR_NULL);
+                // The pair's entries (in point order) are DEALT over the lanes of its groups -- lane 2 g + h of the build
+                // kernel takes words 4 h .. 4 h + 3 of group g -- so that at every step neighbouring lanes read the T rows
+                // of neighbouring points: rows a track length apart fall into different LDS banks, where a contiguous cut
+                // (eight consecutive points per group) put the lanes of one pair 8 tracks apart = the same banks.
+                const size_t cnt = pair_cnt[l], G = (cnt + PAIR_RUN - 1) / PAIR_RUN, slots = 2 * G;
+                const size_t w0 = s.pair_entries.size();
+                s.pair_entries.resize(w0 + G * PAIR_RUN, PAIR_NULL);
+                for (size_t k = 0; k < cnt; ++k) {
+                    const size_t slot = k % slots, step = k / slots;  // step < PAIR_RUN / 2
+                    s.pair_entries[w0 + (slot >> 1) * PAIR_RUN + (slot & 1) * (PAIR_RUN / 2) + step] = sorted[i + k];
+                }
+                n_groups += (int32_t)G;
                 i = j;
             }
             s.ck_pgrp.push_back(n_groups);
