@@ -338,12 +338,13 @@ int do_pcg(BaHandle *h, int *iters_out) {
     return BA_OK;
 }
 
-// dense Cholesky solve of S x = -g_red (small systems); *ok = false when S is not positive definite
-int do_dense(BaHandle *h, bool *ok) {
+// dense Cholesky solve of S x = -g_red (small systems), launched only; *launched = false when there is nothing to solve
+int do_dense(BaHandle *h, bool *launched) {
     hipStream_t st = h->stream;
     const int n = h->sym.n_free * 6;
-    *ok = true;
+    *launched = false;
     if (n == 0) return BA_OK;
+    *launched = true;
     if (h->dense_a.n == 0) {
         HIPCHK(h->dense_a.alloc((size_t)n * n));
         HIPCHK(h->dense_info.alloc(1));
@@ -355,19 +356,16 @@ int do_dense(BaHandle *h, bool *ok) {
     hipLaunchKernelGGL(k_dense_cholesky_solve, dim3(1), dim3(1024), 0, st, n, h->dense_a.p, h->gred, h->px.p,
                        h->dense_info.p);
     HIPCHK(hipGetLastError());
-    int info = 0;
-    HIPCHK(hipMemcpyAsync(&info, h->dense_info.p, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    *ok = (info == 0);
-    return BA_OK;
+    return BA_OK;  // (the pivot flag in dense_info is read together with the step's outcome, see do_step)
 }
 
-// block-banded Cholesky solve of S x = -g_red; *ok = false when S is not positive definite
-int do_banded(BaHandle *h, bool *ok) {
+// block-banded Cholesky solve of S x = -g_red, launched only
+int do_banded(BaHandle *h, bool *launched) {
     hipStream_t st = h->stream;
     const int N = h->sym.n_free, B = h->sym.band;
-    *ok = true;
+    *launched = false;
     if (N == 0) return BA_OK;
+    *launched = true;
     if (h->band_l.n != band_l_doubles(N, B)) {
         HIPCHK(h->band_l.alloc(band_l_doubles(N, B)));
         HIPCHK(h->band_y.alloc(band_vec_doubles(N, B)));
@@ -377,33 +375,14 @@ int do_banded(BaHandle *h, bool *ok) {
     }
     const BandWork w{h->band_l.p, h->band_y.p, h->band_g.p, h->band_mid.p, h->dense_info.p};
     HIPCHK(band_solve_launch(st, N, B, h->n_upper, h->upper_keys.p, h->S, h->gred, h->px.p, w));
-    int info = 0;
-    HIPCHK(hipMemcpyAsync(&info, h->dense_info.p, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    *ok = (info == 0);
-    return BA_OK;
+    return BA_OK;  // (pivot flag: see do_step)
 }
 
-// one LM trial step from the current (built) state; leaves the decision in h->hstate
-int do_step(BaHandle *h) {
+// the part of a trial step behind the linear solve: camera update, back-substitution + trial cost, reductions, decision
+int step_tail(BaHandle *h, const int *solve_info) {
     hipStream_t st = h->stream;
     const Symbolic &s = h->sym;
-    int pcg_it = 0;
     int e;
-    const int n_red = s.n_free * 6;
-    bool solved = false;
-    const int ls = h->opt.linear_solver;
-    const bool can_dense = n_red <= BA_DENSE_MAX, can_band = s.band <= BA_BAND_MAX;
-    if ((ls == BA_SOLVER_AUTO || ls == BA_SOLVER_DENSE_CHOLESKY) && can_dense) {
-        if ((e = do_dense(h, &solved))) return e;
-        if (!solved) h->dense_fallbacks++;
-    } else if ((ls == BA_SOLVER_AUTO || ls == BA_SOLVER_BANDED_CHOLESKY || ls == BA_SOLVER_DENSE_CHOLESKY) && can_band) {
-        if ((e = do_banded(h, &solved))) return e;
-        if (!solved) h->dense_fallbacks++;
-        if (h->opt.verbose >= 3) { fprintf(stderr, "[ba_hip r%d] dense solved=%d\n", h->rank, (int)solved); fflush(stderr); }
-    }
-    if (!solved && (e = do_pcg(h, &pcg_it))) return e;
-    h->total_pcg += pcg_it;
     if (h->coll && s.n_free > 0 && (e = call_coll(h, h->px.p, (int64_t)s.n_free * 6, BA_BROADCAST0))) return e;
     const int cur = h->cur, tr = cur ^ 1;
     hipLaunchKernelGGL(k_cam_update, dim3((s.n_cams + 63) / 64), dim3(64), 0, st, s.n_cams, h->cam_free.p, h->pose[cur].p,
@@ -432,10 +411,46 @@ int do_step(BaHandle *h) {
     hipLaunchKernelGGL(k_add_scalar, dim3(1), dim3(1), 0, st, h->step_sums.p + 3, h->x2_const);
     if (h->coll && (e = call_coll(h, h->step_sums.p, 4, BA_REDUCE_SUM))) return e;
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(1), 0, st, h->state.p, h->step_sums.p, h->cam_sums.p, 0.0,
-                       h->opt.ftol, h->opt.xtol);
+                       h->opt.ftol, h->opt.xtol, solve_info);
     HIPCHK(hipGetLastError());
+    return BA_OK;
+}
+
+// one LM trial step from the current (built) state; leaves the decision in h->hstate
+int do_step(BaHandle *h) {
+    const Symbolic &s = h->sym;
+    int pcg_it = 0;
+    int e;
+    const int n_red = s.n_free * 6;
+    bool direct = false;
+    const int ls = h->opt.linear_solver;
+    const bool can_dense = n_red <= BA_DENSE_MAX, can_band = s.band <= BA_BAND_MAX;
+    if ((ls == BA_SOLVER_AUTO || ls == BA_SOLVER_DENSE_CHOLESKY) && can_dense) {
+        if ((e = do_dense(h, &direct))) return e;
+    } else if ((ls == BA_SOLVER_AUTO || ls == BA_SOLVER_BANDED_CHOLESKY || ls == BA_SOLVER_DENSE_CHOLESKY) && can_band) {
+        if ((e = do_banded(h, &direct))) return e;
+    }
+    if (direct) {
+        // The direct solvers leave a pivot flag on the device.  The rest of the step is queued behind them without
+        // looking at it (no host round trip in the middle of the step); a step whose flag is set is void -- k_decide
+        // leaves the LM state alone -- and is repeated with PCG.
+        if (getenv("BA_DEBUG_FAIL_DIRECT"))  // test hook: pretend the factorisation met a bad pivot
+            HIPCHK(hipMemsetAsync(h->dense_info.p, 1, sizeof(int), h->stream));
+        if ((e = step_tail(h, h->dense_info.p))) return e;
+        if ((e = read_state(h))) return e;  // (k_decide copies the flag into the state: one copy brings both)
+        const int info = h->hstate.solve_info;
+        if (h->opt.verbose >= 3) { fprintf(stderr, "[ba_hip r%d] direct solve info=%d\n", h->rank, info); fflush(stderr); }
+        if (info == 0) {
+            if (h->hstate.accept) h->cur ^= 1;
+            return BA_OK;
+        }
+        h->dense_fallbacks++;
+    }
+    if ((e = do_pcg(h, &pcg_it))) return e;
+    h->total_pcg += pcg_it;
+    if ((e = step_tail(h, nullptr))) return e;
     if ((e = read_state(h))) return e;
-    if (h->hstate.accept) h->cur = tr;
+    if (h->hstate.accept) h->cur ^= 1;
     return BA_OK;
 }
 

@@ -30,7 +30,9 @@ struct LmState {
     double gmax;      // ||g||_inf at the current state
     double dF;
     int accept, status, iter, n_accept;
-    int terminate, pad0, pad1, pad2;
+    int terminate;
+    int solve_info;   // pivot flag of the direct solver behind the last k_decide (!= 0: the step was void)
+    int pad1, pad2;
     double floor;     // current curvature floor in [floor_min, 1]: 1 = IRLS (far from the minimum), see k_decide
     double floor_min;
 };
@@ -879,7 +881,12 @@ __global__ __launch_bounds__(256) void k_state_after_build(LmState *st, const do
 
 // after a trial step: gain ratio, accept / reject, damping update, termination (scipy _lsq/common.py:705-717)
 // step[0..3] = pred, F_trial, |dp|^2, |x_p|^2 (all-reduced); cams[0..1] = |dc|^2, |x_c|^2 (replicated)
-__global__ void k_decide(LmState *st, const double *step, const double *cams, double x2_const, double ftol, double xtol) {
+// solve_info (may be null): != 0 when the direct solver met a non-positive pivot -- the step is void, the state stays
+// as it is and the host repeats the step with PCG
+__global__ void k_decide(LmState *st, const double *step, const double *cams, double x2_const, double ftol, double xtol,
+                         const int *solve_info) {
+    st->solve_info = solve_info ? *solve_info : 0;
+    if (st->solve_info != 0) return;
     const double pred = step[0], Ft = step[1];
     const double F = st->F;
     const double dF = F - Ft;

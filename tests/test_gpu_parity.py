@@ -178,6 +178,21 @@ def test_pcg_and_dense_cholesky_agree(gpu):
     assert np.allclose(out["pcg"][1].cam_pose, out["dense_cholesky"][1].cam_pose, atol=1e-4)
 
 
+def test_failed_direct_solve_falls_back_to_pcg(gpu, monkeypatch):
+    """A direct factorisation that reports a bad pivot voids the step (the rest of the step was queued behind it
+    without a host round trip): the LM state is untouched and the step is repeated with PCG -- same path as a PCG solve."""
+    p = synthetic.make_street(30, 800, 3500, seed=33, outlier_frac=0.02)
+    a1, a2 = _capi.Arrays.from_dict(p), _capi.Arrays.from_dict(p)
+    s_pcg = _capi.solve(a1, loss="huber", f_scale=1.0, max_iter=30, linear_solver="pcg", pcg_tol=1e-10)
+    monkeypatch.setenv("BA_DEBUG_FAIL_DIRECT", "1")
+    s_fb = _capi.solve(a2, loss="huber", f_scale=1.0, max_iter=30, linear_solver="dense_cholesky", pcg_tol=1e-10)
+    monkeypatch.delenv("BA_DEBUG_FAIL_DIRECT")
+    assert s_fb["pcg_iterations"] > 0
+    assert s_fb["status"] == s_pcg["status"] and s_fb["iterations"] == s_pcg["iterations"]
+    assert abs(s_fb["final_cost"] - s_pcg["final_cost"]) <= 1e-9 * s_pcg["final_cost"]
+    np.testing.assert_allclose(a2.cam_pose, a1.cam_pose, rtol=1e-6, atol=1e-8)
+
+
 def test_banded_and_dense_cholesky_agree(gpu):
     """Street sequence (co-visibility band 15 cameras wide): the block-banded factorisation gives the
     same LM path as the dense one."""
