@@ -1,11 +1,16 @@
 // Dense fp64 Cholesky solve of the reduced camera system for SMALL camera counts
 // (6 * free cameras <= BA_DENSE_MAX: the reference's own workloads -- 9 to 46 free cameras).
-// One workgroup, blocked right-looking factorisation with the 32x32 panels staged in LDS,
+// One workgroup, blocked right-looking factorisation (32x32 diagonal blocks factored by one wave in registers),
 // followed by the two triangular solves.  Larger systems use the block-Jacobi PCG
 // (block-sparse S); a multi-workgroup MFMA f64 factorisation for 10k-unknown systems is not
 // written yet.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "ba_device.h"
+#include "ba_banded.h"  // band_wave_sync
 
 #define BA_DENSE_MAX 768
 #define BA_NB 32
@@ -30,125 +35,270 @@ __global__ void k_dense_assemble(int n_upper, const long long *__restrict__ keys
     }
 }
 
-// x = -A^{-1} g by Cholesky; A is overwritten by its lower factor.  info = 0 or the 1-based index of
-// the first non-positive pivot (then x is not valid).
-__global__ __launch_bounds__(1024) void k_dense_cholesky_solve(int n, double *__restrict__ A, const double *__restrict__ g,
-                                                               double *__restrict__ x, int *__restrict__ info) {
-    __shared__ double sL[BA_NB][BA_NB + 1];
-    __shared__ double sA[BA_NB][BA_NB + 1];
-    __shared__ double sB[BA_NB][BA_NB + 1];
+#define BA_DENSE_THREADS 512
+#define BA_PS 34                 // doubles per panel row in LDS (16-byte aligned rows, 4 banks apart)
+#define BA_DENSE_LDS_ROWS 448     // panel rows that fit in LDS next to the static arrays (448 * 34 * 8 = 119 KB)
+#ifdef BA_DENSE_TIMING
+#define BA_DT(i) do { if (tid == 0) { const long long t_ = __builtin_amdgcn_s_memtime(); dt[i] += t_ - t_prev; t_prev = t_; } } while (0)
+#else
+#define BA_DT(i) do { } while (0)
+#endif
+
+// x = -A^{-1} g by Cholesky; A (row-major, lower triangle used) is overwritten by its lower factor.  info = 0 or the
+// 1-based index of the first non-positive pivot (then x is not valid).  One workgroup of 8 waves, blocked right-looking:
+//   1. the 32x32 diagonal block is factored by ONE wave in registers (lane = row; the pivot row's entries travel through
+//      readlane and a 32-double LDS column, no workgroup barrier inside the block),
+//   2. the panel below it: one row per lane, row <- row L_kk^-T with the inverse diagonal (no divides),
+//   3. the trailing update: every wave takes 32x32 blocks of the lower triangle, a lane a 4x4 tile of one, operands read
+//      from the panel in L2 in strips of four columns,
+// then blocked forward / backward substitution with the same one-wave diagonal solves.  n is a multiple of 6 (even), so
+// every row starts 16-byte aligned.
+__global__ __launch_bounds__(BA_DENSE_THREADS) void k_dense_cholesky_solve(int n, double *__restrict__ A, const double *__restrict__ g,
+                                                                           double *__restrict__ x, int *__restrict__ info, int lds_rows) {
+    extern __shared__ __attribute__((aligned(16))) double sPanel[];  // [lds_rows][BA_PS]: the panel of the current block column
+    __shared__ double sL[BA_NB][BA_NB + 1];   // factored diagonal block (lower), for the panel solve
+    __shared__ double sInv[BA_NB];            // 1 / diagonal of that block
+    __shared__ double sColL[BA_NB];           // the scaled column j of the block being factored
+    __shared__ double sRed[BA_DENSE_THREADS / BA_NB][BA_NB + 1];
     __shared__ double sY[BA_DENSE_MAX];
     __shared__ int sBad;
-    const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tx = tid & 31, ty = tid >> 5;
+    constexpr int NW = BA_DENSE_THREADS / 64;
     const int nb = (n + BA_NB - 1) / BA_NB;
     if (tid == 0) sBad = 0;
     __syncthreads();
+#ifdef BA_DENSE_TIMING
+    long long dt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime();
+#endif
 
     for (int kb = 0; kb < nb; ++kb) {
         const int k0 = kb * BA_NB;
         const int kw = (n - k0 < BA_NB) ? n - k0 : BA_NB;
-        // 1. diagonal block -> LDS, unblocked Cholesky there
-        sL[ty][tx] = (ty < kw && tx <= ty) ? A[(size_t)(k0 + ty) * n + k0 + tx] : ((ty == tx) ? 1.0 : 0.0);
-        __syncthreads();
-        for (int j = 0; j < kw; ++j) {
-            if (tid == 0) {
-                const double d = sL[j][j];
-                if (!(d > 0.0) && sBad == 0) sBad = k0 + j + 1;
-                sL[j][j] = sqrt(d > 0.0 ? d : 1.0);
+        // ---- 1. diagonal block: wave 0 factors it in LDS; lanes r and r + 32 share row r (alternate columns), wave-level
+        // synchronisation only.  (A register-resident row per lane would be the natural form, but the compiler turns the
+        // 32 x 32 unrolled triangle into ~370 spilled registers.)
+        if (wave == 0) {
+            const int r = tx, hi = lane >> 5;
+            {
+                // (all sixteen loads in flight: a rolled loop would wait for each of them in turn)
+                const double *ap = &A[(size_t)(k0 + (r < kw ? r : 0)) * n + k0];
+                double v[BA_NB / 2];
+#pragma unroll
+                for (int t = 0; t < BA_NB / 2; ++t) v[t] = ap[(hi + 2 * t) < kw ? hi + 2 * t : 0];
+#pragma unroll
+                for (int t = 0; t < BA_NB / 2; ++t) {
+                    const int c = hi + 2 * t;
+                    sL[r][c] = (r < kw && c < kw && c <= r) ? v[t] : ((c == r) ? 1.0 : 0.0);
+                }
             }
-            __syncthreads();
-            if (ty == 0 && tx > j && tx < kw) sL[tx][j] /= sL[j][j];
-            __syncthreads();
-            if (ty > j && ty < kw && tx > j && tx <= ty) sL[ty][tx] -= sL[ty][j] * sL[tx][j];
-            __syncthreads();
+            band_wave_sync();
+            int bad = 0;
+            // per column: pivot and own entry (one LDS round trip), scaled column to sColL (and into the block), sync,
+            // then the row update in ONE batch -- all loads before the FMAs -- and sync
+            auto update = [&](const int j, const double l, auto nt) {
+                constexpr int NT = decltype(nt)::value;
+                double cj[NT], rc[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int c = j + 1 + hi + 2 * t, cc = c <= r ? c : r;
+                    cj[t] = sColL[cc];
+                    rc[t] = sL[r][cc];
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int c = j + 1 + hi + 2 * t;
+                    if (c <= r) sL[r][c] = fma(-l, cj[t], rc[t]);
+                }
+            };
+            for (int j = 0; j < BA_NB; ++j) {
+                const double d = sL[j][j];
+                if (!(d > 0.0) && bad == 0) bad = k0 + j + 1;
+                const double rs = rsqrt_nr(d > 0.0 ? d : 1.0);
+                const double l = sL[r][j] * rs;             // row j: sqrt(d); rows below: L(r, j); rows above: 0
+                if (hi == 0) {
+                    sColL[r] = l;
+                    if (r >= j) sL[r][j] = l;               // (nobody reads column j of the block again in this factorisation)
+                }
+                band_wave_sync();
+                // row r, columns j+1 .. r: this lane takes c = j + 1 + hi + 2 t
+                if (j < BA_NB / 2 - 1) update(j, l, std::integral_constant<int, BA_NB / 2>());
+                else update(j, l, std::integral_constant<int, BA_NB / 4 + 1>());
+                band_wave_sync();
+            }
+            if (hi == 0) {
+                sInv[r] = 1.0 / sL[r][r];
+                if (r < kw) {
+                    double *op = &A[(size_t)(k0 + r) * n + k0];
+                    for (int c = 0; c <= r; ++c) op[c] = sL[r][c];
+                }
+            }
+            if (lane == 0 && bad != 0 && sBad == 0) sBad = bad;
         }
-        if (ty < kw && tx <= ty) A[(size_t)(k0 + ty) * n + k0 + tx] = sL[ty][tx];
-        // 2. panel below the diagonal block: row_i <- row_i L_kk^{-T}, one row per lane
-        for (int i = k0 + kw + tid; i < n; i += 1024) {
+        __syncthreads();
+        BA_DT(0);
+        // ---- 2. panel below the diagonal block: row_i <- row_i L_kk^{-T}, one row per lane
+        for (int i = k0 + kw + tid; i < n; i += BA_DENSE_THREADS) {
             double row[BA_NB];
             double *ap = &A[(size_t)i * n + k0];
 #pragma unroll
             for (int c = 0; c < BA_NB; ++c) row[c] = (c < kw) ? ap[c] : 0.0;
+            // The address of row c of L is made to depend on entry c - 1 (an empty asm): left alone, the scheduler
+            // fetches all 496 entries of L ahead of the arithmetic and spills ~900 registers.
+            int z = 0;
 #pragma unroll
             for (int c = 0; c < BA_NB; ++c) {
                 double v = row[c];
+                const double *lr = &sL[c][0] + z;
 #pragma unroll
-                for (int k = 0; k < c; ++k) v -= row[k] * sL[c][k];
-                row[c] = v / sL[c][c];
+                for (int k = 0; k < c; ++k) v = fma(-row[k], lr[k], v);
+                row[c] = v * sInv[c];
+                asm volatile("" : "+v"(z) : "v"(row[c]));
             }
 #pragma unroll
             for (int c = 0; c < BA_NB; ++c)
                 if (c < kw) ap[c] = row[c];
+            const int pr = i - (k0 + kw);
+            if (pr < lds_rows) {
+#pragma unroll
+                for (int c = 0; c < BA_NB; c += 2) *reinterpret_cast<double2 *>(&sPanel[pr * BA_PS + c]) = make_double2(row[c], row[c + 1]);
+            }
         }
         __syncthreads();
-        // 3. trailing update A[ib, jb] -= P_ib P_jb^T for kb < jb <= ib
-        for (int ib = kb + 1; ib < nb; ++ib) {
-            const int r = ib * BA_NB + ty;
-            sA[ty][tx] = (r < n && tx < kw) ? A[(size_t)r * n + k0 + tx] : 0.0;
-            for (int jb = kb + 1; jb <= ib; ++jb) {
-                const int rj = jb * BA_NB + ty;
-                __syncthreads();
-                sB[ty][tx] = (rj < n && tx < kw) ? A[(size_t)rj * n + k0 + tx] : 0.0;
-                __syncthreads();
-                double acc = 0.0;
+        BA_DT(1);
+        // ---- 3. trailing update A[ib, jb] -= P_ib P_jb^T, kb < jb <= ib: one 32x32 block per wave and trip
+        {
+            const int m = nb - kb - 1;             // block rows / columns left
+            const bool in_lds = n - k0 - BA_NB <= lds_rows;
+            const int r4 = (lane >> 3) * 4, c4 = (lane & 7) * 4;
+            int ib = 0, jb = 0;                    // block pair number `wave`, then every NW-th, in row-major triangular order
+            for (int skip = wave; skip > 0; --skip) { if (++jb > ib) { ++ib; jb = 0; } }
+            while (ib < m) {
+                const int rb = (kb + 1 + ib) * BA_NB + r4, cb = (kb + 1 + jb) * BA_NB + c4;
+                const double *pa[4], *pb[4];  // (generic pointers: LDS when the panel fits there, else the copy in L2)
 #pragma unroll
-                for (int k = 0; k < BA_NB; ++k) acc += sA[ty][k] * sB[tx][k];
-                const int c = jb * BA_NB + tx;
-                if (r < n && c < n && c <= r) A[(size_t)r * n + c] -= acc;
+                for (int q = 0; q < 4; ++q) {
+                    const int ra = rb + q < n ? rb + q : n - 1, rc = cb + q < n ? cb + q : n - 1;
+                    pa[q] = in_lds ? &sPanel[(ra - k0 - BA_NB) * BA_PS] : &A[(size_t)ra * n + k0];
+                    pb[q] = in_lds ? &sPanel[(rc - k0 - BA_NB) * BA_PS] : &A[(size_t)rc * n + k0];
+                }
+                // the tile's old values are fetched together with the first strips (sixteen read-modify-writes at the end
+                // would be sixteen L2 round trips in a row: the stores may alias the loads)
+                double acc[4][4], old[4][4];  // (old: used only at the end, so its latency hides behind the products)
+                double *pc[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    pc[q] = &A[(size_t)(rb + q < n ? rb + q : n - 1) * n + cb];
+                    const double2 c0 = *reinterpret_cast<const double2 *>(pc[q]), c1 = *reinterpret_cast<const double2 *>(pc[q] + 2);
+                    old[q][0] = c0.x; old[q][1] = c0.y; old[q][2] = c1.x; old[q][3] = c1.y;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) acc[q][p] = 0.0;
+                }
+#pragma unroll 2
+                for (int kc = 0; kc < BA_NB; kc += 4) {
+                    double2 a[4][2], bq[4][2];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        a[q][0] = *reinterpret_cast<const double2 *>(pa[q] + kc);
+                        a[q][1] = *reinterpret_cast<const double2 *>(pa[q] + kc + 2);
+                        bq[q][0] = *reinterpret_cast<const double2 *>(pb[q] + kc);
+                        bq[q][1] = *reinterpret_cast<const double2 *>(pb[q] + kc + 2);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int p = 0; p < 4; ++p)
+                            acc[q][p] += a[q][0].x * bq[p][0].x + a[q][0].y * bq[p][0].y + a[q][1].x * bq[p][1].x + a[q][1].y * bq[p][1].y;
+                }
+                // (columns of the strip beyond kw belong to no panel: the last block is the only short one, and it has no trailing part)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const int rr = rb + q, cc = cb + p;
+                        if (rr < n && cc <= rr) pc[q][p] = old[q][p] - acc[q][p];
+                    }
+                for (int skip = NW; skip > 0; --skip) { if (++jb > ib) { ++ib; jb = 0; } }
             }
-            __syncthreads();
         }
+        __syncthreads();
+        BA_DT(2);
     }
     if (tid == 0) *info = sBad;
     if (sBad != 0) return;
 
-    // forward substitution L y = -g
-    for (int i = tid; i < n; i += 1024) sY[i] = -g[i];
+    // ---- forward substitution L y = -g
+    for (int i = tid; i < n; i += BA_DENSE_THREADS) sY[i] = -g[i];
     __syncthreads();
     for (int kb = 0; kb < nb; ++kb) {
         const int k0 = kb * BA_NB;
         const int kw = (n - k0 < BA_NB) ? n - k0 : BA_NB;
-        sL[ty][tx] = (ty < kw && tx <= ty) ? A[(size_t)(k0 + ty) * n + k0 + tx] : ((ty == tx) ? 1.0 : 0.0);
-        __syncthreads();
-        for (int j = 0; j < kw; ++j) {
-            if (tid == 0) sY[k0 + j] /= sL[j][j];
-            __syncthreads();
-            if (ty == 0 && tx > j && tx < kw) sY[k0 + tx] -= sL[tx][j] * sY[k0 + j];
-            __syncthreads();
+        if (wave == 0) {
+            const int r = tx;
+            const double *ap = &A[(size_t)(k0 + (r < kw ? r : 0)) * n + k0];
+            double lrow[BA_NB], inv = 1.0;
+#pragma unroll
+            for (int c = 0; c < BA_NB; ++c) {
+                const double v = ap[c < kw ? c : 0];
+                lrow[c] = (r < kw && c < r) ? v : 0.0;
+                if (c == r && r < kw) inv = 1.0 / v;
+            }
+            double y = (r < kw) ? sY[k0 + r] : 0.0;
+#pragma unroll
+            for (int j = 0; j < BA_NB; ++j) {
+                const double yj = readlane_f64(y * inv, j);
+                y = (r == j) ? yj : fma(-lrow[j], yj, y);  // (lrow[j] = 0 for the lanes above row j)
+            }
+            if (lane < kw) sY[k0 + r] = y;
         }
-        for (int i = k0 + kw + tid; i < n; i += 1024) {
+        __syncthreads();
+        for (int i = k0 + kw + tid; i < n; i += BA_DENSE_THREADS) {
             const double *ap = &A[(size_t)i * n + k0];
             double s = 0.0;
-            for (int c = 0; c < kw; ++c) s += ap[c] * sY[k0 + c];
+#pragma unroll 8
+            for (int c = 0; c < kw; ++c) s = fma(ap[c], sY[k0 + c], s);
             sY[i] -= s;
         }
         __syncthreads();
     }
-    // backward substitution L^T x = y
+    BA_DT(3);
+    // ---- backward substitution L^T x = y
     for (int kb = nb - 1; kb >= 0; --kb) {
         const int k0 = kb * BA_NB;
         const int kw = (n - k0 < BA_NB) ? n - k0 : BA_NB;
         // subtract the already solved part: column tx of the panel, rows strided by ty
         double part = 0.0;
         if (tx < kw)
-            for (int i = k0 + kw + ty; i < n; i += BA_NB) part += A[(size_t)i * n + k0 + tx] * sY[i];
-        sA[ty][tx] = part;
-        sL[ty][tx] = (ty < kw && tx <= ty) ? A[(size_t)(k0 + ty) * n + k0 + tx] : ((ty == tx) ? 1.0 : 0.0);
+            for (int i = k0 + kw + ty; i < n; i += BA_DENSE_THREADS / BA_NB) part = fma(A[(size_t)i * n + k0 + tx], sY[i], part);
+        sRed[ty][tx] = part;
         __syncthreads();
-        if (ty == 0 && tx < kw) {
+        if (wave == 0) {
+            const int r = tx;
             double s = 0.0;
-            for (int k = 0; k < BA_NB; ++k) s += sA[k][tx];
-            sY[k0 + tx] -= s;
+#pragma unroll
+            for (int k = 0; k < BA_DENSE_THREADS / BA_NB; ++k) s += sRed[k][r];
+            // column r of L_kk: L(j, r), j > r
+            double lcol[BA_NB], inv = 1.0;
+#pragma unroll
+            for (int j = 0; j < BA_NB; ++j) {
+                const double v = A[(size_t)(k0 + (j < kw ? j : 0)) * n + k0 + (r < kw ? r : 0)];
+                lcol[j] = (r < kw && j < kw && j > r) ? v : 0.0;
+                if (j == r && r < kw) inv = 1.0 / v;
+            }
+            double xv = (r < kw) ? sY[k0 + r] - s : 0.0;
+#pragma unroll
+            for (int j = BA_NB - 1; j >= 0; --j) {
+                const double xj = readlane_f64(xv * inv, j);
+                xv = (r == j) ? xj : fma(-lcol[j], xj, xv);
+            }
+            if (lane < kw) sY[k0 + r] = xv;
         }
         __syncthreads();
-        for (int j = kw - 1; j >= 0; --j) {
-            if (tid == 0) sY[k0 + j] /= sL[j][j];
-            __syncthreads();
-            if (ty == 0 && tx < j) sY[k0 + tx] -= sL[j][tx] * sY[k0 + j];
-            __syncthreads();
-        }
     }
-    for (int i = tid; i < n; i += 1024) x[i] = sY[i];
+    for (int i = tid; i < n; i += BA_DENSE_THREADS) x[i] = sY[i];
+    BA_DT(4);
+#ifdef BA_DENSE_TIMING
+    if (tid == 0) printf("[dense n=%d] diag %lld panel %lld trailing %lld forward %lld backward %lld (s_memtime ticks)\n", n, dt[0], dt[1], dt[2], dt[3], dt[4]);
+#endif
 }
 
 }  // namespace ba

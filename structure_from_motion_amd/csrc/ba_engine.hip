@@ -346,15 +346,26 @@ int do_dense(BaHandle *h, bool *launched) {
     if (n == 0) return BA_OK;
     *launched = true;
     if (h->dense_a.n == 0) {
-        HIPCHK(h->dense_a.alloc((size_t)n * n));
+        HIPCHK(h->dense_a.alloc((size_t)n * n + 8));  // (+8: the trailing update reads whole 4-column strips of the last row)
         HIPCHK(h->dense_info.alloc(1));
     }
     HIPCHK(hipMemsetAsync(h->dense_a.p, 0, (size_t)n * n * sizeof(double), st));
     const int ne = h->n_upper * 36;
     hipLaunchKernelGGL(k_dense_assemble, dim3((ne + 255) / 256), dim3(256), 0, st, h->n_upper, h->upper_keys.p, h->S, n,
                        h->dense_a.p);
-    hipLaunchKernelGGL(k_dense_cholesky_solve, dim3(1), dim3(1024), 0, st, n, h->dense_a.p, h->gred, h->px.p,
-                       h->dense_info.p);
+    {
+        // the panel of a block column lives in dynamic LDS when it fits (beyond the 64 KB a kernel gets by default)
+        const int rows = n > BA_NB ? n - BA_NB : 0, lds_rows = rows < BA_DENSE_LDS_ROWS ? rows : BA_DENSE_LDS_ROWS;
+        const size_t dyn = (size_t)lds_rows * BA_PS * sizeof(double);
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_cholesky_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       BA_DENSE_LDS_ROWS * BA_PS * (int)sizeof(double)));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_dense_cholesky_solve, dim3(1), dim3(BA_DENSE_THREADS), dyn, st, n, h->dense_a.p, h->gred, h->px.p,
+                           h->dense_info.p, lds_rows);
+    }
     HIPCHK(hipGetLastError());
     return BA_OK;  // (the pivot flag in dense_info is read together with the step's outcome, see do_step)
 }
