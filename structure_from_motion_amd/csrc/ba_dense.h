@@ -58,7 +58,7 @@ __global__ __launch_bounds__(BA_DENSE_THREADS) void k_dense_cholesky_solve(int n
     extern __shared__ __attribute__((aligned(16))) double sPanel[];  // [lds_rows][BA_PS]: the panel of the current block column
     __shared__ double sL[BA_NB][BA_NB + 1];   // factored diagonal block (lower), for the panel solve
     __shared__ double sInv[BA_NB];            // 1 / diagonal of that block
-    __shared__ double sColL[BA_NB];           // the scaled column j of the block being factored
+    __shared__ double sColL[2][BA_NB];        // the two scaled columns of the block being factored
     __shared__ double sRed[BA_DENSE_THREADS / BA_NB][BA_NB + 1];
     __shared__ double sY[BA_DENSE_MAX];
     __shared__ int sBad;
@@ -93,36 +93,44 @@ __global__ __launch_bounds__(BA_DENSE_THREADS) void k_dense_cholesky_solve(int n
             }
             band_wave_sync();
             int bad = 0;
-            // per column: pivot and own entry (one LDS round trip), scaled column to sColL (and into the block), sync,
-            // then the row update in ONE batch -- all loads before the FMAs -- and sync
-            auto update = [&](const int j, const double l, auto nt) {
+            // TWO columns per step (the step is bound by its LDS round trips and wave syncs, not by its width): the 2x2
+            // pivot block and this row's two entries in one round trip, the scaled columns to sColL (and into the block),
+            // sync, then the rank-2 update of the row in ONE batch -- all loads before the FMAs -- and sync
+            auto update = [&](const int j, const double l0, const double l1, auto nt) {
                 constexpr int NT = decltype(nt)::value;
-                double cj[NT], rc[NT];
+                double c0[NT], c1[NT], rc[NT];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    const int c = j + 1 + hi + 2 * t, cc = c <= r ? c : r;
-                    cj[t] = sColL[cc];
+                    const int c = j + 2 + hi + 2 * t, cc = c <= r ? c : r;
+                    c0[t] = sColL[0][cc];
+                    c1[t] = sColL[1][cc];
                     rc[t] = sL[r][cc];
                 }
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    const int c = j + 1 + hi + 2 * t;
-                    if (c <= r) sL[r][c] = fma(-l, cj[t], rc[t]);
+                    const int c = j + 2 + hi + 2 * t;
+                    if (c <= r) sL[r][c] = fma(-l1, c1[t], fma(-l0, c0[t], rc[t]));
                 }
             };
-            for (int j = 0; j < BA_NB; ++j) {
-                const double d = sL[j][j];
-                if (!(d > 0.0) && bad == 0) bad = k0 + j + 1;
-                const double rs = rsqrt_nr(d > 0.0 ? d : 1.0);
-                const double l = sL[r][j] * rs;             // row j: sqrt(d); rows below: L(r, j); rows above: 0
+            for (int j = 0; j < BA_NB; j += 2) {
+                const double d00 = sL[j][j], d10 = sL[j + 1][j], d11 = sL[j + 1][j + 1], a0 = sL[r][j], a1 = sL[r][j + 1];
+                if (!(d00 > 0.0) && bad == 0) bad = k0 + j + 1;
+                const double rs0 = rsqrt_nr(d00 > 0.0 ? d00 : 1.0);
+                const double l10 = d10 * rs0, e11 = d11 - l10 * l10;
+                if (!(e11 > 0.0) && bad == 0) bad = k0 + j + 2;
+                const double rs1 = rsqrt_nr(e11 > 0.0 ? e11 : 1.0);
+                const double l0 = a0 * rs0;                                      // row j: sqrt(d00); rows above: 0
+                const double l1 = r > j ? (a1 - l0 * l10) * rs1 : 0.0;           // row j + 1: sqrt(e11); rows above: 0
                 if (hi == 0) {
-                    sColL[r] = l;
-                    if (r >= j) sL[r][j] = l;               // (nobody reads column j of the block again in this factorisation)
+                    sColL[0][r] = l0;
+                    sColL[1][r] = l1;
+                    if (r >= j) sL[r][j] = l0;                // (nobody reads these two columns of the block again here)
+                    if (r > j) sL[r][j + 1] = l1;
                 }
                 band_wave_sync();
-                // row r, columns j+1 .. r: this lane takes c = j + 1 + hi + 2 t
-                if (j < BA_NB / 2 - 1) update(j, l, std::integral_constant<int, BA_NB / 2>());
-                else update(j, l, std::integral_constant<int, BA_NB / 4 + 1>());
+                // row r, columns j+2 .. r: this lane takes c = j + 2 + hi + 2 t
+                if (j < BA_NB / 2 - 2) update(j, l0, l1, std::integral_constant<int, BA_NB / 2 - 1>());
+                else update(j, l0, l1, std::integral_constant<int, BA_NB / 4>());
                 band_wave_sync();
             }
             if (hi == 0) {
@@ -174,13 +182,6 @@ __global__ __launch_bounds__(BA_DENSE_THREADS) void k_dense_cholesky_solve(int n
             for (int skip = wave; skip > 0; --skip) { if (++jb > ib) { ++ib; jb = 0; } }
             while (ib < m) {
                 const int rb = (kb + 1 + ib) * BA_NB + r4, cb = (kb + 1 + jb) * BA_NB + c4;
-                const double *pa[4], *pb[4];  // (generic pointers: LDS when the panel fits there, else the copy in L2)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int ra = rb + q < n ? rb + q : n - 1, rc = cb + q < n ? cb + q : n - 1;
-                    pa[q] = in_lds ? &sPanel[(ra - k0 - BA_NB) * BA_PS] : &A[(size_t)ra * n + k0];
-                    pb[q] = in_lds ? &sPanel[(rc - k0 - BA_NB) * BA_PS] : &A[(size_t)rc * n + k0];
-                }
                 // the tile's old values are fetched together with the first strips (sixteen read-modify-writes at the end
                 // would be sixteen L2 round trips in a row: the stores may alias the loads)
                 double acc[4][4], old[4][4];  // (old: used only at the end, so its latency hides behind the products)
@@ -193,21 +194,38 @@ __global__ __launch_bounds__(BA_DENSE_THREADS) void k_dense_cholesky_solve(int n
 #pragma unroll
                     for (int p = 0; p < 4; ++p) acc[q][p] = 0.0;
                 }
-#pragma unroll 2
-                for (int kc = 0; kc < BA_NB; kc += 4) {
-                    double2 a[4][2], bq[4][2];
+                // operands: the panel rows of the tile's rows and columns, from LDS when the panel fits there (two separate
+                // loops, so that the LDS one is compiled to ds_read and not to generic loads), else from its copy in L2
+                auto products = [&](const double *const (&pa)[4], const double *const (&pb)[4]) {
+#pragma unroll 1
+                    for (int kc = 0; kc < BA_NB; kc += 4) {
+                        double2 a[4][2], bq[4][2];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        a[q][0] = *reinterpret_cast<const double2 *>(pa[q] + kc);
-                        a[q][1] = *reinterpret_cast<const double2 *>(pa[q] + kc + 2);
-                        bq[q][0] = *reinterpret_cast<const double2 *>(pb[q] + kc);
-                        bq[q][1] = *reinterpret_cast<const double2 *>(pb[q] + kc + 2);
+                        for (int q = 0; q < 4; ++q) {
+                            a[q][0] = *reinterpret_cast<const double2 *>(pa[q] + kc);
+                            a[q][1] = *reinterpret_cast<const double2 *>(pa[q] + kc + 2);
+                            bq[q][0] = *reinterpret_cast<const double2 *>(pb[q] + kc);
+                            bq[q][1] = *reinterpret_cast<const double2 *>(pb[q] + kc + 2);
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int p = 0; p < 4; ++p)
+                                acc[q][p] += a[q][0].x * bq[p][0].x + a[q][0].y * bq[p][0].y + a[q][1].x * bq[p][1].x + a[q][1].y * bq[p][1].y;
                     }
+                };
+                int ra[4], rc[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-#pragma unroll
-                        for (int p = 0; p < 4; ++p)
-                            acc[q][p] += a[q][0].x * bq[p][0].x + a[q][0].y * bq[p][0].y + a[q][1].x * bq[p][1].x + a[q][1].y * bq[p][1].y;
+                for (int q = 0; q < 4; ++q) { ra[q] = rb + q < n ? rb + q : n - 1; rc[q] = cb + q < n ? cb + q : n - 1; }
+                if (in_lds) {
+                    const int o = k0 + BA_NB;
+                    const double *const pa[4] = {&sPanel[(ra[0] - o) * BA_PS], &sPanel[(ra[1] - o) * BA_PS], &sPanel[(ra[2] - o) * BA_PS], &sPanel[(ra[3] - o) * BA_PS]};
+                    const double *const pb[4] = {&sPanel[(rc[0] - o) * BA_PS], &sPanel[(rc[1] - o) * BA_PS], &sPanel[(rc[2] - o) * BA_PS], &sPanel[(rc[3] - o) * BA_PS]};
+                    products(pa, pb);
+                } else {
+                    const double *const pa[4] = {&A[(size_t)ra[0] * n + k0], &A[(size_t)ra[1] * n + k0], &A[(size_t)ra[2] * n + k0], &A[(size_t)ra[3] * n + k0]};
+                    const double *const pb[4] = {&A[(size_t)rc[0] * n + k0], &A[(size_t)rc[1] * n + k0], &A[(size_t)rc[2] * n + k0], &A[(size_t)rc[3] * n + k0]};
+                    products(pa, pb);
                 }
                 // (columns of the strip beyond kw belong to no panel: the last block is the only short one, and it has no trailing part)
 #pragma unroll
