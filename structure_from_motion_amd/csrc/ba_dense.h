@@ -56,8 +56,8 @@ __global__ void k_dense_assemble(int n_upper, const long long *__restrict__ keys
 __global__ __launch_bounds__(BA_DENSE_THREADS) void k_dense_cholesky_solve(int n, double *__restrict__ A, const double *__restrict__ g,
                                                                            double *__restrict__ x, int *__restrict__ info, int lds_rows) {
     extern __shared__ __attribute__((aligned(16))) double sPanel[];  // [lds_rows][BA_PS]: the panel of the current block column
-    __shared__ double sL[BA_NB][BA_NB + 1];   // factored diagonal block (lower), for the panel solve
-    __shared__ double sInv[BA_NB];            // 1 / diagonal of that block
+    __shared__ double sLd[2][BA_NB][BA_NB + 1];  // [kb & 1]: factored diagonal block (lower), for the panel solve
+    __shared__ double sInvd[2][BA_NB];           // 1 / diagonal of that block
     __shared__ double sColL[2][BA_NB];        // the two scaled columns of the block being factored
     __shared__ double sRed[BA_DENSE_THREADS / BA_NB][BA_NB + 1];
     __shared__ double sY[BA_DENSE_MAX];
@@ -71,79 +71,88 @@ __global__ __launch_bounds__(BA_DENSE_THREADS) void k_dense_cholesky_solve(int n
     long long dt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime();
 #endif
 
+    // ---- 1. diagonal block (wave 0 only): wave 0 factors it in LDS; lanes r and r + 32 share row r (alternate columns), wave-level
+    // synchronisation only.  (A register-resident row per lane would be the natural form, but the compiler turns the
+    // 32 x 32 unrolled triangle into ~370 spilled registers.)
+    auto factor_diag = [&](const int kbx) {
+        const int k0 = kbx * BA_NB;
+        const int kw = (n - k0 < BA_NB) ? n - k0 : BA_NB;
+        double (&sL)[BA_NB][BA_NB + 1] = sLd[kbx & 1];
+        double (&sInv)[BA_NB] = sInvd[kbx & 1];
+        const int r = tx, hi = lane >> 5;
+        {
+            // (all sixteen loads in flight: a rolled loop would wait for each of them in turn)
+            const double *ap = &A[(size_t)(k0 + (r < kw ? r : 0)) * n + k0];
+            double v[BA_NB / 2];
+#pragma unroll
+            for (int t = 0; t < BA_NB / 2; ++t) v[t] = ap[(hi + 2 * t) < kw ? hi + 2 * t : 0];
+#pragma unroll
+            for (int t = 0; t < BA_NB / 2; ++t) {
+                const int c = hi + 2 * t;
+                sL[r][c] = (r < kw && c < kw && c <= r) ? v[t] : ((c == r) ? 1.0 : 0.0);
+            }
+        }
+        band_wave_sync();
+        int bad = 0;
+        // TWO columns per step (the step is bound by its LDS round trips and wave syncs, not by its width): the 2x2
+        // pivot block and this row's two entries in one round trip, the scaled columns to sColL (and into the block),
+        // sync, then the rank-2 update of the row in ONE batch -- all loads before the FMAs -- and sync
+        auto update = [&](const int j, const double l0, const double l1, auto nt) {
+            constexpr int NT = decltype(nt)::value;
+            double c0[NT], c1[NT], rc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int c = j + 2 + hi + 2 * t, cc = c <= r ? c : r;
+                c0[t] = sColL[0][cc];
+                c1[t] = sColL[1][cc];
+                rc[t] = sL[r][cc];
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int c = j + 2 + hi + 2 * t;
+                if (c <= r) sL[r][c] = fma(-l1, c1[t], fma(-l0, c0[t], rc[t]));
+            }
+        };
+        for (int j = 0; j < BA_NB; j += 2) {
+            const double d00 = sL[j][j], d10 = sL[j + 1][j], d11 = sL[j + 1][j + 1], a0 = sL[r][j], a1 = sL[r][j + 1];
+            if (!(d00 > 0.0) && bad == 0) bad = k0 + j + 1;
+            const double rs0 = rsqrt_nr(d00 > 0.0 ? d00 : 1.0);
+            const double l10 = d10 * rs0, e11 = d11 - l10 * l10;
+            if (!(e11 > 0.0) && bad == 0) bad = k0 + j + 2;
+            const double rs1 = rsqrt_nr(e11 > 0.0 ? e11 : 1.0);
+            const double l0 = a0 * rs0;                                      // row j: sqrt(d00); rows above: 0
+            const double l1 = r > j ? (a1 - l0 * l10) * rs1 : 0.0;           // row j + 1: sqrt(e11); rows above: 0
+            if (hi == 0) {
+                sColL[0][r] = l0;
+                sColL[1][r] = l1;
+                if (r >= j) sL[r][j] = l0;                // (nobody reads these two columns of the block again here)
+                if (r > j) sL[r][j + 1] = l1;
+            }
+            band_wave_sync();
+            // row r, columns j+2 .. r: this lane takes c = j + 2 + hi + 2 t
+            if (j < BA_NB / 2 - 2) update(j, l0, l1, std::integral_constant<int, BA_NB / 2 - 1>());
+            else update(j, l0, l1, std::integral_constant<int, BA_NB / 4>());
+            band_wave_sync();
+        }
+        if (hi == 0) {
+            sInv[r] = 1.0 / sL[r][r];
+            if (r < kw) {
+                double *op = &A[(size_t)(k0 + r) * n + k0];
+                for (int c = 0; c <= r; ++c) op[c] = sL[r][c];
+            }
+        }
+        if (lane == 0 && bad != 0 && sBad == 0) sBad = bad;
+    };
+    // The diagonal block of column kb + 1 is factored by wave 0 WHILE the other waves finish the trailing update of
+    // column kb (wave 0 updates that block first): the two serial parts of a block column overlap.
+    if (wave == 0) factor_diag(0);
+    __syncthreads();
+    BA_DT(0);
     for (int kb = 0; kb < nb; ++kb) {
         const int k0 = kb * BA_NB;
         const int kw = (n - k0 < BA_NB) ? n - k0 : BA_NB;
-        // ---- 1. diagonal block: wave 0 factors it in LDS; lanes r and r + 32 share row r (alternate columns), wave-level
-        // synchronisation only.  (A register-resident row per lane would be the natural form, but the compiler turns the
-        // 32 x 32 unrolled triangle into ~370 spilled registers.)
-        if (wave == 0) {
-            const int r = tx, hi = lane >> 5;
-            {
-                // (all sixteen loads in flight: a rolled loop would wait for each of them in turn)
-                const double *ap = &A[(size_t)(k0 + (r < kw ? r : 0)) * n + k0];
-                double v[BA_NB / 2];
-#pragma unroll
-                for (int t = 0; t < BA_NB / 2; ++t) v[t] = ap[(hi + 2 * t) < kw ? hi + 2 * t : 0];
-#pragma unroll
-                for (int t = 0; t < BA_NB / 2; ++t) {
-                    const int c = hi + 2 * t;
-                    sL[r][c] = (r < kw && c < kw && c <= r) ? v[t] : ((c == r) ? 1.0 : 0.0);
-                }
-            }
-            band_wave_sync();
-            int bad = 0;
-            // TWO columns per step (the step is bound by its LDS round trips and wave syncs, not by its width): the 2x2
-            // pivot block and this row's two entries in one round trip, the scaled columns to sColL (and into the block),
-            // sync, then the rank-2 update of the row in ONE batch -- all loads before the FMAs -- and sync
-            auto update = [&](const int j, const double l0, const double l1, auto nt) {
-                constexpr int NT = decltype(nt)::value;
-                double c0[NT], c1[NT], rc[NT];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int c = j + 2 + hi + 2 * t, cc = c <= r ? c : r;
-                    c0[t] = sColL[0][cc];
-                    c1[t] = sColL[1][cc];
-                    rc[t] = sL[r][cc];
-                }
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int c = j + 2 + hi + 2 * t;
-                    if (c <= r) sL[r][c] = fma(-l1, c1[t], fma(-l0, c0[t], rc[t]));
-                }
-            };
-            for (int j = 0; j < BA_NB; j += 2) {
-                const double d00 = sL[j][j], d10 = sL[j + 1][j], d11 = sL[j + 1][j + 1], a0 = sL[r][j], a1 = sL[r][j + 1];
-                if (!(d00 > 0.0) && bad == 0) bad = k0 + j + 1;
-                const double rs0 = rsqrt_nr(d00 > 0.0 ? d00 : 1.0);
-                const double l10 = d10 * rs0, e11 = d11 - l10 * l10;
-                if (!(e11 > 0.0) && bad == 0) bad = k0 + j + 2;
-                const double rs1 = rsqrt_nr(e11 > 0.0 ? e11 : 1.0);
-                const double l0 = a0 * rs0;                                      // row j: sqrt(d00); rows above: 0
-                const double l1 = r > j ? (a1 - l0 * l10) * rs1 : 0.0;           // row j + 1: sqrt(e11); rows above: 0
-                if (hi == 0) {
-                    sColL[0][r] = l0;
-                    sColL[1][r] = l1;
-                    if (r >= j) sL[r][j] = l0;                // (nobody reads these two columns of the block again here)
-                    if (r > j) sL[r][j + 1] = l1;
-                }
-                band_wave_sync();
-                // row r, columns j+2 .. r: this lane takes c = j + 2 + hi + 2 t
-                if (j < BA_NB / 2 - 2) update(j, l0, l1, std::integral_constant<int, BA_NB / 2 - 1>());
-                else update(j, l0, l1, std::integral_constant<int, BA_NB / 4>());
-                band_wave_sync();
-            }
-            if (hi == 0) {
-                sInv[r] = 1.0 / sL[r][r];
-                if (r < kw) {
-                    double *op = &A[(size_t)(k0 + r) * n + k0];
-                    for (int c = 0; c <= r; ++c) op[c] = sL[r][c];
-                }
-            }
-            if (lane == 0 && bad != 0 && sBad == 0) sBad = bad;
-        }
-        __syncthreads();
-        BA_DT(0);
+        double (&sL)[BA_NB][BA_NB + 1] = sLd[kb & 1];
+        double (&sInv)[BA_NB] = sInvd[kb & 1];
         // ---- 2. panel below the diagonal block: row_i <- row_i L_kk^{-T}, one row per lane
         for (int i = k0 + kw + tid; i < n; i += BA_DENSE_THREADS) {
             double row[BA_NB];
@@ -178,9 +187,7 @@ __global__ __launch_bounds__(BA_DENSE_THREADS) void k_dense_cholesky_solve(int n
             const int m = nb - kb - 1;             // block rows / columns left
             const bool in_lds = n - k0 - BA_NB <= lds_rows;
             const int r4 = (lane >> 3) * 4, c4 = (lane & 7) * 4;
-            int ib = 0, jb = 0;                    // block pair number `wave`, then every NW-th, in row-major triangular order
-            for (int skip = wave; skip > 0; --skip) { if (++jb > ib) { ++ib; jb = 0; } }
-            while (ib < m) {
+            auto do_pair = [&](const int ib, const int jb) {
                 const int rb = (kb + 1 + ib) * BA_NB + r4, cb = (kb + 1 + jb) * BA_NB + c4;
                 // the tile's old values are fetched together with the first strips (sixteen read-modify-writes at the end
                 // would be sixteen L2 round trips in a row: the stores may alias the loads)
@@ -235,7 +242,21 @@ __global__ __launch_bounds__(BA_DENSE_THREADS) void k_dense_cholesky_solve(int n
                         const int rr = rb + q, cc = cb + p;
                         if (rr < n && cc <= rr) pc[q][p] = old[q][p] - acc[q][p];
                     }
-                for (int skip = NW; skip > 0; --skip) { if (++jb > ib) { ++ib; jb = 0; } }
+            };
+            if (m > 0) {
+                if (wave == 0) {
+                    // the next diagonal block first, then its factorisation while the other waves do the rest
+                    do_pair(0, 0);
+                    __threadfence_block();  // (this wave reads back what its lanes have just stored)
+                    factor_diag(kb + 1);
+                } else {
+                    int ib = 0, jb = 0;  // block pairs 1, 2, ... in row-major triangular order, dealt over waves 1 .. NW-1
+                    for (int skip = wave; skip > 0; --skip) { if (++jb > ib) { ++ib; jb = 0; } }
+                    while (ib < m) {
+                        do_pair(ib, jb);
+                        for (int skip = NW - 1; skip > 0; --skip) { if (++jb > ib) { ++ib; jb = 0; } }
+                    }
+                }
             }
         }
         __syncthreads();
