@@ -167,6 +167,7 @@ struct BaHandle {
     DevBuf<long long> upper_keys;
     DevBuf<int> dense_info;
     int dense_fallbacks = 0;
+    bool dense_attr_set = false;
     DevBuf<LmState> state;
     LmState hstate{};
     PcgScalars hpcg{};
@@ -357,11 +358,10 @@ int do_dense(BaHandle *h, bool *launched) {
         // the panel of a block column lives in dynamic LDS when it fits (beyond the 64 KB a kernel gets by default)
         const int rows = n > BA_NB ? n - BA_NB : 0, lds_rows = rows < BA_DENSE_LDS_ROWS ? rows : BA_DENSE_LDS_ROWS;
         const size_t dyn = (size_t)lds_rows * BA_PS * sizeof(double);
-        static bool attr_set = false;
-        if (!attr_set) {
+        if (!h->dense_attr_set) {  // (per handle: the attribute belongs to the function on the handle's device)
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_cholesky_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        BA_DENSE_LDS_ROWS * BA_PS * (int)sizeof(double)));
-            attr_set = true;
+            h->dense_attr_set = true;
         }
         hipLaunchKernelGGL(k_dense_cholesky_solve, dim3(1), dim3(BA_DENSE_THREADS), dyn, st, n, h->dense_a.p, h->gred, h->px.p,
                            h->dense_info.p, lds_rows);
