@@ -234,8 +234,7 @@ __global__ __launch_bounds__(BA_BAND_THREADS) void k_band_cholesky_solve(const B
     __syncthreads();
 
     // rank-6 update of this thread's block with column jp (operands in sL[jp & 1]); publishes column jp + 2
-    auto window_update = [&](const int jp) {
-        int jm = (jp + 2) % P;
+    auto window_update = [&](const int jp, const int jm /* (jp + 2) mod P */) {
         int m1 = s1 - jm, m2 = s2 - jm;
         if (m1 < 0) m1 += P;
         if (m2 < 0) m2 += P;
@@ -287,6 +286,9 @@ __global__ __launch_bounds__(BA_BAND_THREADS) void k_band_cholesky_solve(const B
             if (e < B * 36) Lb[((size_t)jc * P + 1) * 36 + e] = cv[k];
         }
     };
+    // j mod P and j mod (P + 1) are carried from column to column (P is a run-time value: a modulo costs a division)
+    int mP = 0, mPb = 0;
+    auto wrapP = [&](int v) { return v >= P ? v - P : v; };
     auto column_step = [&](const int j, double &pre) {
         // ---- phase 1 ----
         BA_BAND_STAMP(0);
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(BA_BAND_THREADS) void k_band_cholesky_solve(const B
                 const bool yl = tid == B * 6;
                 const int d = tid / 6 + 1, a = tid - (d - 1) * 6;
                 double xr[6];
-                const double *Ar = yl ? &sB[(j % Pb) * 6] : &sA[d * 36 + a * 6];
+                const double *Ar = yl ? &sB[mPb * 6] : &sA[d * 36 + a * 6];
 #pragma unroll
                 for (int b = 0; b < 6; ++b) {
                     double s = Ar[b];
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(BA_BAND_THREADS) void k_band_cholesky_solve(const B
                 for (int b = 0; b < 6; ++b) o[b] = xr[b];
             }
         } else if (is_win && j > 0) {
-            window_update(j - 1);
+            window_update(j - 1, wrapP(mP + 1));
         }
         BA_BAND_STAMP(2);
         __syncthreads();
@@ -344,10 +346,10 @@ __global__ __launch_bounds__(BA_BAND_THREADS) void k_band_cholesky_solve(const B
         }
         if (is_win) {
             // pairs of the slot that left the window (row j + 1) take the blocks of row rn = j + P + 1
-            const int sn = (j + 1) % P;
+            const int sn = wrapP(mP + 1);
             if (s1 == sn || s2 == sn) {
                 const int so = (s1 == sn) ? s2 : s1;
-                int mo = so - (j + 2) % P;
+                int mo = so - wrapP(wrapP(mP + 1) + 1);
                 if (mo < 0) mo += P;
                 mo += 2;                     // offset of the other row from j, in [2, P + 1] (P + 1: the diagonal pair)
                 const int d = P + 1 - mo;    // block (rn, rn - d)
@@ -368,20 +370,22 @@ __global__ __launch_bounds__(BA_BAND_THREADS) void k_band_cholesky_solve(const B
             // right-hand-side update b_{j+d} -= L(j+d, j) y_j; y_j to HBM
             if (aux < B * 6) {
                 const int d = aux / 6 + 1, a = aux - (d - 1) * 6;
-                const int sl = (j + d) % Pb;
+                const int sl = mPb + d >= Pb ? mPb + d - Pb : mPb + d;
                 const double *l = &sL[j & 1][(d - 1) * 36 + a * 6];
                 double s = sB[sl * 6 + a];
 #pragma unroll
                 for (int k = 0; k < 6; ++k) s = fma(-l[k], sY[k], s);
                 sB[sl * 6 + a] = s;
             } else if (aux >= 120 && aux < 126) {
-                sB[((j + P + 1) % Pb) * 6 + (aux - 120)] = sNew[P * 36 + (aux - 120)];
+                sB[mPb * 6 + (aux - 120)] = sNew[P * 36 + (aux - 120)];  // slot (j + P + 1) mod (P + 1) = j mod (P + 1)
                 ywork[(size_t)j * 6 + (aux - 120)] = sY[aux - 120];
             }
         }
         BA_BAND_STAMP(4);
         __syncthreads();
         BA_BAND_STAMP(5);
+        mP = wrapP(mP + 1);
+        mPb = mPb + 1 >= Pb ? 0 : mPb + 1;
     };
     for (int j = 0; j < n_elim; j += 2) {
         column_step(j, pa);
@@ -394,7 +398,7 @@ __global__ __launch_bounds__(BA_BAND_THREADS) void k_band_cholesky_solve(const B
         // eliminated column has been applied to the window), the rest in the registers of the window threads.
         const int je = n_elim;
         double *mid = args.mid_l, *mid_g = args.mid_g;
-        if (is_win && je > 0) window_update(je - 1);
+        if (is_win && je > 0) window_update(je - 1, wrapP(mP + 1));  // (mP = je mod P here)
         __syncthreads();
         // block (je + tr, je + tc) of THIS side, tr >= tc -> band storage of the separator system (column = lower camera)
         auto emit = [&](int tr, int tc, int a, int b, double v) {
