@@ -1,9 +1,9 @@
 // Dense fp64 Cholesky solve of the reduced camera system for SMALL camera counts
 // (6 * free cameras <= BA_DENSE_MAX: the reference's own workloads -- 9 to 46 free cameras).
 // One workgroup, blocked right-looking factorisation (32x32 diagonal blocks factored by one wave in registers),
-// followed by the two triangular solves.  Larger systems use the block-Jacobi PCG
-// (block-sparse S); a multi-workgroup MFMA f64 factorisation for 10k-unknown systems is not
-// written yet.
+// trailing update on the fp64 matrix cores), followed by the two triangular solves.  Larger systems use the banded
+// Cholesky or the block-Jacobi PCG (block-sparse S); a multi-workgroup factorisation for 10k-unknown dense systems is
+// not written.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -16,6 +16,8 @@
 #define BA_NB 32
 
 namespace ba {
+
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 
 // S (upper 6x6 blocks) -> full symmetric dense matrix, row-major, leading dimension n
 __global__ void k_dense_assemble(int n_upper, const long long *__restrict__ keys, const double *__restrict__ S, int n,
@@ -49,8 +51,8 @@ __global__ void k_dense_assemble(int n_upper, const long long *__restrict__ keys
 //   1. the 32x32 diagonal block is factored by ONE wave in registers (lane = row; the pivot row's entries travel through
 //      readlane and a 32-double LDS column, no workgroup barrier inside the block),
 //   2. the panel below it: one row per lane, row <- row L_kk^-T with the inverse diagonal (no divides),
-//   3. the trailing update: every wave takes 32x32 blocks of the lower triangle, a lane a 4x4 tile of one, operands read
-//      from the panel in L2 in strips of four columns,
+//   3. the trailing update: every wave takes 32x32 blocks of the lower triangle as 2x2 fp64 MFMA tiles (16x16x4), operands
+//      read from the panel's copy in LDS (or in L2 when it does not fit),
 // then blocked forward / backward substitution with the same one-wave diagonal solves.  n is a multiple of 6 (even), so
 // every row starts 16-byte aligned.
 __global__ __launch_bounds__(BA_DENSE_THREADS) void k_dense_cholesky_solve(int n, double *__restrict__ A, const double *__restrict__ g,
@@ -185,63 +187,68 @@ __global__ __launch_bounds__(BA_DENSE_THREADS) void k_dense_cholesky_solve(int n
         // ---- 3. trailing update A[ib, jb] -= P_ib P_jb^T, kb < jb <= ib: one 32x32 block per wave and trip
         {
             const int m = nb - kb - 1;             // block rows / columns left
-            const bool in_lds = n - k0 - BA_NB <= lds_rows;
-            const int r4 = (lane >> 3) * 4, c4 = (lane & 7) * 4;
+            // One wave computes the 32x32 product as 2x2 MFMA tiles (v_mfma_f64_16x16x4_f64): operand A is P_ib[l15][4 kc + l4],
+            // operand B is P_jb[l15][4 kc + l4] -- ONE double per lane, tile and k-step (a 4x4 register tile on the vector
+            // ALUs reads four times as much LDS per FMA and was bound by those reads) -- and the result tile has
+            // col = lane & 15, row = (lane >> 4) + 4 v in element v of the accumulator.
+            const int l15 = lane & 15, l4 = lane >> 4;
             auto do_pair = [&](const int ib, const int jb) {
-                const int rb = (kb + 1 + ib) * BA_NB + r4, cb = (kb + 1 + jb) * BA_NB + c4;
-                // the tile's old values are fetched together with the first strips (sixteen read-modify-writes at the end
-                // would be sixteen L2 round trips in a row: the stores may alias the loads)
-                double acc[4][4], old[4][4];  // (old: used only at the end, so its latency hides behind the products)
-                double *pc[4];
+                const int rb = (kb + 1 + ib) * BA_NB, cb = (kb + 1 + jb) * BA_NB;
+                const bool diag = ib == jb;  // (its upper right tile is not needed)
+                // the tile's old values are fetched up front (sixteen read-modify-writes at the end would be sixteen L2
+                // round trips in a row: the stores may alias the loads), their latency hides behind the products
+                mfma_d4 acc[2][2];
+                double old[2][2][4];
+                const int ccl = cb + l15;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    pc[q] = &A[(size_t)(rb + q < n ? rb + q : n - 1) * n + cb];
-                    const double2 c0 = *reinterpret_cast<const double2 *>(pc[q]), c1 = *reinterpret_cast<const double2 *>(pc[q] + 2);
-                    old[q][0] = c0.x; old[q][1] = c0.y; old[q][2] = c1.x; old[q][3] = c1.y;
+                for (int ri = 0; ri < 2; ++ri)
 #pragma unroll
-                    for (int p = 0; p < 4; ++p) acc[q][p] = 0.0;
-                }
-                // operands: the panel rows of the tile's rows and columns, from LDS when the panel fits there (two separate
-                // loops, so that the LDS one is compiled to ds_read and not to generic loads), else from its copy in L2
-                auto products = [&](const double *const (&pa)[4], const double *const (&pb)[4]) {
-#pragma unroll 1
-                    for (int kc = 0; kc < BA_NB; kc += 4) {
-                        double2 a[4][2], bq[4][2];
+                    for (int ci = 0; ci < 2; ++ci) {
+                        acc[ri][ci] = mfma_d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            a[q][0] = *reinterpret_cast<const double2 *>(pa[q] + kc);
-                            a[q][1] = *reinterpret_cast<const double2 *>(pa[q] + kc + 2);
-                            bq[q][0] = *reinterpret_cast<const double2 *>(pb[q] + kc);
-                            bq[q][1] = *reinterpret_cast<const double2 *>(pb[q] + kc + 2);
+                        for (int v = 0; v < 4; ++v) {
+                            const int rr = rb + ri * 16 + l4 + 4 * v, cc = ccl + ci * 16;
+                            old[ri][ci][v] = A[(size_t)(rr < n ? rr : n - 1) * n + (cc < n ? cc : n - 1)];
                         }
+                    }
+                // operands from LDS when the panel fits there (two separate loops, so that the LDS one is compiled to
+                // ds_read and not to generic loads), else from the panel's copy in L2
+                auto products = [&](const double *const (&pa)[2], const double *const (&pb)[2]) {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
-#pragma unroll
-                            for (int p = 0; p < 4; ++p)
-                                acc[q][p] += a[q][0].x * bq[p][0].x + a[q][0].y * bq[p][0].y + a[q][1].x * bq[p][1].x + a[q][1].y * bq[p][1].y;
+                    for (int kc = 0; kc < BA_NB; kc += 4) {
+                        const double a0 = pa[0][kc], a1 = pa[1][kc], b0 = pb[0][kc], b1 = pb[1][kc];
+                        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+                        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+                        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+                        if (!diag) acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
                     }
                 };
-                int ra[4], rc[4];
+                int ra[2], rc[2];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { ra[q] = rb + q < n ? rb + q : n - 1; rc[q] = cb + q < n ? cb + q : n - 1; }
-                if (in_lds) {
-                    const int o = k0 + BA_NB;
-                    const double *const pa[4] = {&sPanel[(ra[0] - o) * BA_PS], &sPanel[(ra[1] - o) * BA_PS], &sPanel[(ra[2] - o) * BA_PS], &sPanel[(ra[3] - o) * BA_PS]};
-                    const double *const pb[4] = {&sPanel[(rc[0] - o) * BA_PS], &sPanel[(rc[1] - o) * BA_PS], &sPanel[(rc[2] - o) * BA_PS], &sPanel[(rc[3] - o) * BA_PS]};
-                    products(pa, pb);
-                } else {
-                    const double *const pa[4] = {&A[(size_t)ra[0] * n + k0], &A[(size_t)ra[1] * n + k0], &A[(size_t)ra[2] * n + k0], &A[(size_t)ra[3] * n + k0]};
-                    const double *const pb[4] = {&A[(size_t)rc[0] * n + k0], &A[(size_t)rc[1] * n + k0], &A[(size_t)rc[2] * n + k0], &A[(size_t)rc[3] * n + k0]};
-                    products(pa, pb);
+                for (int q = 0; q < 2; ++q) {
+                    ra[q] = rb + q * 16 + l15 < n ? rb + q * 16 + l15 : n - 1;
+                    rc[q] = cb + q * 16 + l15 < n ? cb + q * 16 + l15 : n - 1;
                 }
+                // (per block row: with more rows than the LDS panel holds, the first lds_rows of them are still read there)
+                const int o = k0 + BA_NB;
+                const bool a_lds = (ib + 1) * BA_NB <= lds_rows || n - o <= lds_rows, b_lds = (jb + 1) * BA_NB <= lds_rows || n - o <= lds_rows;
+                const double *const la[2] = {&sPanel[(a_lds ? ra[0] - o : 0) * BA_PS + l4], &sPanel[(a_lds ? ra[1] - o : 0) * BA_PS + l4]};
+                const double *const lb[2] = {&sPanel[(b_lds ? rc[0] - o : 0) * BA_PS + l4], &sPanel[(b_lds ? rc[1] - o : 0) * BA_PS + l4]};
+                const double *const ga[2] = {&A[(size_t)ra[0] * n + k0 + l4], &A[(size_t)ra[1] * n + k0 + l4]};
+                const double *const gb[2] = {&A[(size_t)rc[0] * n + k0 + l4], &A[(size_t)rc[1] * n + k0 + l4]};
+                if (a_lds) products(la, lb);            // (jb <= ib: b is in LDS whenever a is)
+                else if (b_lds) products(ga, lb);
+                else products(ga, gb);
                 // (columns of the strip beyond kw belong to no panel: the last block is the only short one, and it has no trailing part)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int ri = 0; ri < 2; ++ri)
 #pragma unroll
-                    for (int p = 0; p < 4; ++p) {
-                        const int rr = rb + q, cc = cb + p;
-                        if (rr < n && cc <= rr) pc[q][p] = old[q][p] - acc[q][p];
-                    }
+                    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const int rr = rb + ri * 16 + l4 + 4 * v, cc = ccl + ci * 16;
+                            if (rr < n && cc <= rr) A[(size_t)rr * n + cc] = old[ri][ci][v] - acc[ri][ci][v];
+                        }
             };
             if (m > 0) {
                 if (wave == 0) {
