@@ -211,18 +211,19 @@ def test_banded_and_dense_cholesky_agree(gpu):
 
 def test_dense_cholesky_at_its_size_limit(gpu):
     """128 free cameras = 768 unknowns, the largest dense system: the panel of the first block columns does not fit in
-    LDS, so the MFMA trailing update takes its operands partly from LDS and partly from L2.  Same LM path as PCG."""
+    LDS, so the MFMA trailing update takes its operands partly from LDS and partly from L2.  Same LM path as the
+    other direct solver (PCG solves this chain inexactly, so its path differs in the seventh digit)."""
     p = synthetic.make_street(130, 3000, 13000, seed=44, outlier_frac=0.01, n_fixed=2)
     out = {}
-    for solver in ("pcg", "dense_cholesky"):
+    for solver in ("banded_cholesky", "dense_cholesky"):
         arr = _capi.Arrays.from_dict(p)
-        out[solver] = (_capi.solve(arr, loss="huber", f_scale=1.0, max_iter=20, linear_solver=solver, pcg_tol=1e-12), arr)
-    sp, sd = out["pcg"][0], out["dense_cholesky"][0]
-    assert sd["pcg_iterations"] == 0 and sp["pcg_iterations"] > 0
-    assert sp["iterations"] == sd["iterations"] and sp["accepted"] == sd["accepted"]
+        out[solver] = (_capi.solve(arr, loss="huber", f_scale=1.0, max_iter=20, linear_solver=solver), arr)
+    sb, sd = out["banded_cholesky"][0], out["dense_cholesky"][0]
+    assert sd["pcg_iterations"] == 0 and sb["pcg_iterations"] == 0
+    assert sb["iterations"] == sd["iterations"] and sb["accepted"] == sd["accepted"]
     assert sd["final_cost"] < 0.05 * sd["initial_cost"]
-    assert abs(sp["final_cost"] - sd["final_cost"]) <= 1e-8 * sd["final_cost"]
-    np.testing.assert_allclose(out["dense_cholesky"][1].cam_pose, out["pcg"][1].cam_pose, rtol=1e-5, atol=1e-6)
+    assert abs(sb["final_cost"] - sd["final_cost"]) <= 1e-9 * sd["final_cost"]
+    np.testing.assert_allclose(out["dense_cholesky"][1].cam_pose, out["banded_cholesky"][1].cam_pose, rtol=1e-6, atol=1e-7)
 
 
 def test_set_values_reuses_the_structure(gpu):
