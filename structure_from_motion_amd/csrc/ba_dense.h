@@ -53,21 +53,25 @@ __global__ void k_dense_assemble(int n_upper, const long long *__restrict__ keys
 //   2. the panel below it: one row per lane, row <- row L_kk^-T with the inverse diagonal (no divides),
 //   3. the trailing update: every wave takes 32x32 blocks of the lower triangle as 2x2 fp64 MFMA tiles (16x16x4), operands
 //      read from the panel's copy in LDS (or in L2 when it does not fit),
-// then blocked forward / backward substitution with the same one-wave diagonal solves.  n is a multiple of 6 (even), so
+// the forward substitution rides along in the trailing phase (wave 1, panel still in LDS); then the blocked backward
+// substitution with one-wave diagonal solves.  n is a multiple of 6 (even), so
 // every row starts 16-byte aligned.
 __global__ __launch_bounds__(BA_DENSE_THREADS) void k_dense_cholesky_solve(int n, double *__restrict__ A, const double *__restrict__ g,
                                                                            double *__restrict__ x, int *__restrict__ info, int lds_rows) {
     extern __shared__ __attribute__((aligned(16))) double sPanel[];  // [lds_rows][BA_PS]: the panel of the current block column
-    __shared__ double sLd[2][BA_NB][BA_NB + 1];  // [kb & 1]: factored diagonal block (lower), for the panel solve
+    // [kb & 1]: factored diagonal block (lower), for the panel solve.  (One row and half a column vector of slack: the
+    // row update below reads a fixed number of entries per lane at constant offsets, some of them past the diagonal.)
+    __shared__ double sLd[2][BA_NB + 1][BA_NB + 1];
     __shared__ double sInvd[2][BA_NB];           // 1 / diagonal of that block
-    __shared__ double sColL[2][BA_NB];        // the two scaled columns of the block being factored
-    __shared__ double sRed[BA_DENSE_THREADS / BA_NB][BA_NB + 1];
+    __shared__ double sColL[2][2 * BA_NB];    // the two scaled columns of the block being factored (+ slack)
     __shared__ double sY[BA_DENSE_MAX];
+    __shared__ double sInvAll[BA_DENSE_MAX];     // 1 / diagonal of L, kept for the backward substitution
     __shared__ int sBad;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tx = tid & 31, ty = tid >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tx = tid & 31;
     constexpr int NW = BA_DENSE_THREADS / 64;
     const int nb = (n + BA_NB - 1) / BA_NB;
     if (tid == 0) sBad = 0;
+    for (int i = tid; i < n; i += BA_DENSE_THREADS) sY[i] = -g[i];
     __syncthreads();
 #ifdef BA_DENSE_TIMING
     long long dt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime();
@@ -79,7 +83,7 @@ __global__ __launch_bounds__(BA_DENSE_THREADS) void k_dense_cholesky_solve(int n
     auto factor_diag = [&](const int kbx) {
         const int k0 = kbx * BA_NB;
         const int kw = (n - k0 < BA_NB) ? n - k0 : BA_NB;
-        double (&sL)[BA_NB][BA_NB + 1] = sLd[kbx & 1];
+        double (&sL)[BA_NB + 1][BA_NB + 1] = sLd[kbx & 1];
         double (&sInv)[BA_NB] = sInvd[kbx & 1];
         const int r = tx, hi = lane >> 5;
         {
@@ -101,19 +105,21 @@ __global__ __launch_bounds__(BA_DENSE_THREADS) void k_dense_cholesky_solve(int n
         // sync, then the rank-2 update of the row in ONE batch -- all loads before the FMAs -- and sync
         auto update = [&](const int j, const double l0, const double l1, auto nt) {
             constexpr int NT = decltype(nt)::value;
+            // (one base address per array and constant offsets: with per-entry clamping the address arithmetic of the
+            // 45 loads cost more than the loads; entries past the diagonal are read -- inside the slack -- and dropped)
+            const double *p0 = &sColL[0][j + 2 + hi], *p1 = &sColL[1][j + 2 + hi];
+            double *rp = &sL[0][0] + r * (BA_NB + 1) + j + 2 + hi;
+            const int lim = r - (j + 2 + hi);
             double c0[NT], c1[NT], rc[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const int c = j + 2 + hi + 2 * t, cc = c <= r ? c : r;
-                c0[t] = sColL[0][cc];
-                c1[t] = sColL[1][cc];
-                rc[t] = sL[r][cc];
+                c0[t] = p0[2 * t];
+                c1[t] = p1[2 * t];
+                rc[t] = rp[2 * t];
             }
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int c = j + 2 + hi + 2 * t;
-                if (c <= r) sL[r][c] = fma(-l1, c1[t], fma(-l0, c0[t], rc[t]));
-            }
+            for (int t = 0; t < NT; ++t)
+                if (2 * t <= lim) rp[2 * t] = fma(-l1, c1[t], fma(-l0, c0[t], rc[t]));
         };
         for (int j = 0; j < BA_NB; j += 2) {
             const double d00 = sL[j][j], d10 = sL[j + 1][j], d11 = sL[j + 1][j + 1], a0 = sL[r][j], a1 = sL[r][j + 1];
@@ -137,10 +143,17 @@ __global__ __launch_bounds__(BA_DENSE_THREADS) void k_dense_cholesky_solve(int n
             band_wave_sync();
         }
         if (hi == 0) {
-            sInv[r] = 1.0 / sL[r][r];
+            const double iv = 1.0 / sL[r][r];
+            sInv[r] = iv;
             if (r < kw) {
+                sInvAll[k0 + r] = iv;
                 double *op = &A[(size_t)(k0 + r) * n + k0];
-                for (int c = 0; c <= r; ++c) op[c] = sL[r][c];
+                double w[BA_NB];
+#pragma unroll
+                for (int c = 0; c < BA_NB; ++c) w[c] = sL[r][c];
+#pragma unroll
+                for (int c = 0; c < BA_NB; ++c)
+                    if (c <= r) op[c] = w[c];
             }
         }
         if (lane == 0 && bad != 0 && sBad == 0) sBad = bad;
@@ -153,7 +166,7 @@ __global__ __launch_bounds__(BA_DENSE_THREADS) void k_dense_cholesky_solve(int n
     for (int kb = 0; kb < nb; ++kb) {
         const int k0 = kb * BA_NB;
         const int kw = (n - k0 < BA_NB) ? n - k0 : BA_NB;
-        double (&sL)[BA_NB][BA_NB + 1] = sLd[kb & 1];
+        double (&sL)[BA_NB + 1][BA_NB + 1] = sLd[kb & 1];
         double (&sInv)[BA_NB] = sInvd[kb & 1];
         // ---- 2. panel below the diagonal block: row_i <- row_i L_kk^{-T}, one row per lane
         for (int i = k0 + kw + tid; i < n; i += BA_DENSE_THREADS) {
@@ -250,6 +263,47 @@ __global__ __launch_bounds__(BA_DENSE_THREADS) void k_dense_cholesky_solve(int n
                             if (rr < n && cc <= rr) A[(size_t)rr * n + cc] = old[ri][ci][v] - acc[ri][ci][v];
                         }
             };
+            // Forward substitution L y = -g rides along (wave 1): y of this block column from the factored diagonal block
+            // in LDS, then its contribution leaves the right-hand side of the panel rows -- the panel is still in LDS, a
+            // separate forward pass would fetch all of L from L2 again, two round trips per block column.
+            if (wave == 1) {
+                const int r = tx;
+                double lrow[BA_NB], yb[BA_NB];
+#pragma unroll
+                for (int c = 0; c < BA_NB; ++c) lrow[c] = (c < r) ? sL[r][c] : 0.0;
+                const double inv = sInv[r];
+                double y = (r < kw) ? sY[k0 + r] : 0.0;
+#pragma unroll
+                for (int j = 0; j < BA_NB; ++j) {
+                    const double yj = readlane_f64(y * inv, j);
+                    yb[j] = yj;
+                    y = (r == j) ? yj : fma(-lrow[j], yj, y);  // (lrow[j] = 0 for the lanes above row j)
+                }
+                if (lane < kw) sY[k0 + r] = y;
+                const int rows = n - (k0 + kw), rl = rows < lds_rows ? rows : lds_rows;
+                for (int pr = lane; pr < rl; pr += 64) {
+                    const double *pp = &sPanel[pr * BA_PS];
+                    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                    for (int c = 0; c < BA_NB; c += 2) {
+                        const double2 v = *reinterpret_cast<const double2 *>(pp + c);
+                        s0 = fma(v.x, yb[c], s0);
+                        s1 = fma(v.y, yb[c + 1], s1);
+                    }
+                    sY[k0 + kw + pr] -= s0 + s1;
+                }
+                for (int pr = rl + lane; pr < rows; pr += 64) {
+                    const double *pp = &A[(size_t)(k0 + kw + pr) * n + k0];
+                    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                    for (int c = 0; c < BA_NB; c += 2) {
+                        const double2 v = *reinterpret_cast<const double2 *>(pp + c);
+                        s0 = fma(v.x, yb[c], s0);
+                        s1 = fma(v.y, yb[c + 1], s1);
+                    }
+                    sY[k0 + kw + pr] -= s0 + s1;
+                }
+            }
             if (m > 0) {
                 if (wave == 0) {
                     // the next diagonal block first, then its factorisation while the other waves do the rest
@@ -272,78 +326,58 @@ __global__ __launch_bounds__(BA_DENSE_THREADS) void k_dense_cholesky_solve(int n
     if (tid == 0) *info = sBad;
     if (sBad != 0) return;
 
-    // ---- forward substitution L y = -g
-    for (int i = tid; i < n; i += BA_DENSE_THREADS) sY[i] = -g[i];
-    __syncthreads();
-    for (int kb = 0; kb < nb; ++kb) {
-        const int k0 = kb * BA_NB;
-        const int kw = (n - k0 < BA_NB) ? n - k0 : BA_NB;
-        if (wave == 0) {
-            const int r = tx;
-            const double *ap = &A[(size_t)(k0 + (r < kw ? r : 0)) * n + k0];
-            double lrow[BA_NB], inv = 1.0;
-#pragma unroll
-            for (int c = 0; c < BA_NB; ++c) {
-                const double v = ap[c < kw ? c : 0];
-                lrow[c] = (r < kw && c < r) ? v : 0.0;
-                if (c == r && r < kw) inv = 1.0 / v;
-            }
-            double y = (r < kw) ? sY[k0 + r] : 0.0;
-#pragma unroll
-            for (int j = 0; j < BA_NB; ++j) {
-                const double yj = readlane_f64(y * inv, j);
-                y = (r == j) ? yj : fma(-lrow[j], yj, y);  // (lrow[j] = 0 for the lanes above row j)
-            }
-            if (lane < kw) sY[k0 + r] = y;
-        }
-        __syncthreads();
-        for (int i = k0 + kw + tid; i < n; i += BA_DENSE_THREADS) {
-            const double *ap = &A[(size_t)i * n + k0];
-            double s = 0.0;
-#pragma unroll 8
-            for (int c = 0; c < kw; ++c) s = fma(ap[c], sY[k0 + c], s);
-            sY[i] -= s;
-        }
-        __syncthreads();
-    }
     BA_DT(3);
-    // ---- backward substitution L^T x = y
-    for (int kb = nb - 1; kb >= 0; --kb) {
-        const int k0 = kb * BA_NB;
-        const int kw = (n - k0 < BA_NB) ? n - k0 : BA_NB;
-        // subtract the already solved part: column tx of the panel, rows strided by ty
-        double part = 0.0;
-        if (tx < kw)
-            for (int i = k0 + kw + ty; i < n; i += BA_DENSE_THREADS / BA_NB) part = fma(A[(size_t)i * n + k0 + tx], sY[i], part);
-        sRed[ty][tx] = part;
-        __syncthreads();
-        if (wave == 0) {
+    // ---- backward substitution L^T x = y, right-looking: the solved block leaves the rows above it at once (rows of L,
+    // coalesced, all loads of a thread in flight together); wave 0 fetches the next diagonal block meanwhile
+    {
+        double lcol[BA_NB], inv = 1.0;  // wave 0: column tx of the diagonal block to solve next (L(j, tx), j > tx)
+        auto fetch_diag = [&](const int kbx) {
+            const int k0 = kbx * BA_NB;
+            const int kw = (n - k0 < BA_NB) ? n - k0 : BA_NB;
             const int r = tx;
-            double s = 0.0;
-#pragma unroll
-            for (int k = 0; k < BA_DENSE_THREADS / BA_NB; ++k) s += sRed[k][r];
-            // column r of L_kk: L(j, r), j > r
-            double lcol[BA_NB], inv = 1.0;
 #pragma unroll
             for (int j = 0; j < BA_NB; ++j) {
                 const double v = A[(size_t)(k0 + (j < kw ? j : 0)) * n + k0 + (r < kw ? r : 0)];
                 lcol[j] = (r < kw && j < kw && j > r) ? v : 0.0;
-                if (j == r && r < kw) inv = 1.0 / v;
             }
-            double xv = (r < kw) ? sY[k0 + r] - s : 0.0;
+            inv = (r < kw) ? sInvAll[k0 + r] : 1.0;
+        };
+        if (wave == 0) fetch_diag(nb - 1);
+        for (int kb = nb - 1; kb >= 0; --kb) {
+            const int k0 = kb * BA_NB;
+            const int kw = (n - k0 < BA_NB) ? n - k0 : BA_NB;
+            if (wave == 0) {
+                const int r = tx;
+                double xv = (r < kw) ? sY[k0 + r] : 0.0;
 #pragma unroll
-            for (int j = BA_NB - 1; j >= 0; --j) {
-                const double xj = readlane_f64(xv * inv, j);
-                xv = (r == j) ? xj : fma(-lcol[j], xj, xv);
+                for (int j = BA_NB - 1; j >= 0; --j) {
+                    const double xj = readlane_f64(xv * inv, j);
+                    xv = (r == j) ? xj : fma(-lcol[j], xj, xv);
+                }
+                if (lane < kw) sY[k0 + r] = xv;
             }
-            if (lane < kw) sY[k0 + r] = xv;
+            __syncthreads();
+            if (kb == 0) break;
+            if (wave == 0) fetch_diag(kb - 1);
+            for (int i = tid; i < k0; i += BA_DENSE_THREADS) {
+                double v[BA_NB];
+#pragma unroll
+                for (int c = 0; c < BA_NB; ++c) v[c] = A[(size_t)(k0 + (c < kw ? c : 0)) * n + i];
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int c = 0; c < BA_NB; c += 2) {
+                    s0 = fma(v[c], c < kw ? sY[k0 + c] : 0.0, s0);
+                    s1 = fma(v[c + 1], c + 1 < kw ? sY[k0 + c + 1] : 0.0, s1);
+                }
+                sY[i] -= s0 + s1;
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     for (int i = tid; i < n; i += BA_DENSE_THREADS) x[i] = sY[i];
     BA_DT(4);
 #ifdef BA_DENSE_TIMING
-    if (tid == 0) printf("[dense n=%d] diag %lld panel %lld trailing %lld forward %lld backward %lld (s_memtime ticks)\n", n, dt[0], dt[1], dt[2], dt[3], dt[4]);
+    if (tid == 0) printf("[dense n=%d] diag %lld panel %lld trailing+forward %lld backward %lld (s_memtime ticks)\n", n, dt[0], dt[1], dt[2], dt[4]);
 #endif
 }
 
