@@ -80,13 +80,13 @@ __global__ __launch_bounds__(BA_DENSE_THREADS) void k_dense_cholesky_solve(int n
     // ---- 1. diagonal block (wave 0 only): wave 0 factors it in LDS; lanes r and r + 32 share row r (alternate columns), wave-level
     // synchronisation only.  (A register-resident row per lane would be the natural form, but the compiler turns the
     // 32 x 32 unrolled triangle into ~370 spilled registers.)
-    auto factor_diag = [&](const int kbx) {
+    auto factor_diag = [&](const int kbx, const bool in_place) {
         const int k0 = kbx * BA_NB;
         const int kw = (n - k0 < BA_NB) ? n - k0 : BA_NB;
         double (&sL)[BA_NB + 1][BA_NB + 1] = sLd[kbx & 1];
         double (&sInv)[BA_NB] = sInvd[kbx & 1];
         const int r = tx, hi = lane >> 5;
-        {
+        if (!in_place) {  // (in place: this wave has just written the updated block into sL, see the trailing update)
             // (all sixteen loads in flight: a rolled loop would wait for each of them in turn)
             const double *ap = &A[(size_t)(k0 + (r < kw ? r : 0)) * n + k0];
             double v[BA_NB / 2];
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(BA_DENSE_THREADS) void k_dense_cholesky_solve(int n
     };
     // The diagonal block of column kb + 1 is factored by wave 0 WHILE the other waves finish the trailing update of
     // column kb (wave 0 updates that block first): the two serial parts of a block column overlap.
-    if (wave == 0) factor_diag(0);
+    if (wave == 0) factor_diag(0, false);
     __syncthreads();
     BA_DT(0);
     for (int kb = 0; kb < nb; ++kb) {
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(BA_DENSE_THREADS) void k_dense_cholesky_solve(int n
             // ALUs reads four times as much LDS per FMA and was bound by those reads) -- and the result tile has
             // col = lane & 15, row = (lane >> 4) + 4 v in element v of the accumulator.
             const int l15 = lane & 15, l4 = lane >> 4;
-            auto do_pair = [&](const int ib, const int jb) {
+            auto do_pair = [&](const int ib, const int jb, double (*const next_diag)[BA_NB + 1]) {
                 const int rb = (kb + 1 + ib) * BA_NB, cb = (kb + 1 + jb) * BA_NB;
                 const bool diag = ib == jb;  // (its upper right tile is not needed)
                 // the tile's old values are fetched up front (sixteen read-modify-writes at the end would be sixteen L2
@@ -260,7 +260,11 @@ __global__ __launch_bounds__(BA_DENSE_THREADS) void k_dense_cholesky_solve(int n
 #pragma unroll
                         for (int v = 0; v < 4; ++v) {
                             const int rr = rb + ri * 16 + l4 + 4 * v, cc = ccl + ci * 16;
-                            if (rr < n && cc <= rr) A[(size_t)rr * n + cc] = old[ri][ci][v] - acc[ri][ci][v];
+                            const bool in = rr < n && cc <= rr;
+                            if (next_diag != nullptr)  // the next diagonal block goes straight to where it is factored (padded to 32x32 by the identity)
+                                next_diag[rr - rb][cc - cb] = in ? old[ri][ci][v] - acc[ri][ci][v] : ((cc == rr) ? 1.0 : 0.0);
+                            else if (in)
+                                A[(size_t)rr * n + cc] = old[ri][ci][v] - acc[ri][ci][v];
                         }
             };
             // Forward substitution L y = -g rides along (wave 1): y of this block column from the factored diagonal block
@@ -307,14 +311,13 @@ __global__ __launch_bounds__(BA_DENSE_THREADS) void k_dense_cholesky_solve(int n
             if (m > 0) {
                 if (wave == 0) {
                     // the next diagonal block first, then its factorisation while the other waves do the rest
-                    do_pair(0, 0);
-                    __threadfence_block();  // (this wave reads back what its lanes have just stored)
-                    factor_diag(kb + 1);
+                    do_pair(0, 0, sLd[(kb + 1) & 1]);
+                    factor_diag(kb + 1, true);
                 } else {
                     int ib = 0, jb = 0;  // block pairs 1, 2, ... in row-major triangular order, dealt over waves 1 .. NW-1
                     for (int skip = wave; skip > 0; --skip) { if (++jb > ib) { ++ib; jb = 0; } }
                     while (ib < m) {
-                        do_pair(ib, jb);
+                        do_pair(ib, jb, nullptr);
                         for (int skip = NW - 1; skip > 0; --skip) { if (++jb > ib) { ++ib; jb = 0; } }
                     }
                 }
