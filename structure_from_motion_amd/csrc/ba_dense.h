@@ -1,7 +1,7 @@
 // Dense fp64 Cholesky solve of the reduced camera system for SMALL camera counts
 // (6 * free cameras <= BA_DENSE_MAX: the reference's own workloads -- 9 to 46 free cameras).
-// One workgroup, blocked right-looking factorisation (32x32 diagonal blocks factored by one wave in registers),
-// trailing update on the fp64 matrix cores), followed by the two triangular solves.  Larger systems use the banded
+// One workgroup, blocked right-looking factorisation (32x32 diagonal blocks factored by one wave in LDS, trailing
+// update on the fp64 matrix cores) with the forward substitution fused in, then the backward substitution.  Larger systems use the banded
 // Cholesky or the block-Jacobi PCG (block-sparse S); a multi-workgroup factorisation for 10k-unknown dense systems is
 // not written.
 #pragma once
@@ -48,14 +48,13 @@ __global__ void k_dense_assemble(int n_upper, const long long *__restrict__ keys
 
 // x = -A^{-1} g by Cholesky; A (row-major, lower triangle used) is overwritten by its lower factor.  info = 0 or the
 // 1-based index of the first non-positive pivot (then x is not valid).  One workgroup of 8 waves, blocked right-looking:
-//   1. the 32x32 diagonal block is factored by ONE wave in registers (lane = row; the pivot row's entries travel through
-//      readlane and a 32-double LDS column, no workgroup barrier inside the block),
+//   1. the 32x32 diagonal block is factored by ONE wave in LDS (two lanes per row, two columns per step, wave-level
+//      synchronisation only), overlapped with the trailing update of the column before (look-ahead),
 //   2. the panel below it: one row per lane, row <- row L_kk^-T with the inverse diagonal (no divides),
 //   3. the trailing update: every wave takes 32x32 blocks of the lower triangle as 2x2 fp64 MFMA tiles (16x16x4), operands
 //      read from the panel's copy in LDS (or in L2 when it does not fit),
 // the forward substitution rides along in the trailing phase (wave 1, panel still in LDS); then the blocked backward
-// substitution with one-wave diagonal solves.  n is a multiple of 6 (even), so
-// every row starts 16-byte aligned.
+// substitution with one-wave diagonal solves.  n is a multiple of 6 (even), so every row starts 16-byte aligned.
 __global__ __launch_bounds__(BA_DENSE_THREADS) void k_dense_cholesky_solve(int n, double *__restrict__ A, const double *__restrict__ g,
                                                                            double *__restrict__ x, int *__restrict__ info, int lds_rows) {
     extern __shared__ __attribute__((aligned(16))) double sPanel[];  // [lds_rows][BA_PS]: the panel of the current block column
