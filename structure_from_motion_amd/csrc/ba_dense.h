@@ -173,17 +173,48 @@ __global__ __launch_bounds__(BA_DENSE_THREADS) void k_dense_cholesky_solve(int n
             double *ap = &A[(size_t)i * n + k0];
 #pragma unroll
             for (int c = 0; c < BA_NB; ++c) row[c] = (c < kw) ? ap[c] : 0.0;
-            // The address of row c of L is made to depend on entry c - 1 (an empty asm): left alone, the scheduler
-            // fetches all 496 entries of L ahead of the arithmetic and spills ~900 registers.
+            // Sub-blocks of eight columns: the 8x8 triangle in one LDS round trip, then the later columns lose the eight
+            // solved ones four columns at a time (independent 8-FMA chains).  The empty asm makes each group's address
+            // depend on the group before: left alone, the scheduler fetches all of L ahead and spills.
             int z = 0;
 #pragma unroll
-            for (int c = 0; c < BA_NB; ++c) {
-                double v = row[c];
-                const double *lr = &sL[c][0] + z;
+            for (int b = 0; b < BA_NB / 8; ++b) {
+                const int c0 = 8 * b;
+                {
+                    double l[8][8];
 #pragma unroll
-                for (int k = 0; k < c; ++k) v = fma(-row[k], lr[k], v);
-                row[c] = v * sInv[c];
-                asm volatile("" : "+v"(z) : "v"(row[c]));
+                    for (int i = 1; i < 8; ++i) {
+                        const double *lr = &sL[c0 + i][c0] + z;
+#pragma unroll
+                        for (int k = 0; k < i; ++k) l[i][k] = lr[k];
+                    }
+                    double iv[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) iv[i] = (&sInv[c0 + i])[z];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        double v = row[c0 + i];
+#pragma unroll
+                        for (int k = 0; k < i; ++k) v = fma(-row[c0 + k], l[i][k], v);
+                        row[c0 + i] = v * iv[i];
+                    }
+                    asm volatile("" : "+v"(z) : "v"(row[c0 + 7]));
+                }
+#pragma unroll
+                for (int cg = c0 + 8; cg < BA_NB; cg += 4) {
+                    double l[4][8];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const double *lr = &sL[cg + q][c0] + z;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) l[q][k] = lr[k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) row[cg + q] = fma(-row[c0 + k], l[q][k], row[cg + q]);
+                    asm volatile("" : "+v"(z) : "v"(row[cg + 3]));
+                }
             }
 #pragma unroll
             for (int c = 0; c < BA_NB; ++c)

@@ -6,7 +6,10 @@
 #include <cmath>
 #include <vector>
 #include <random>
-#include "../structure_from_motion_amd/csrc/ba_dense.h"
+#ifndef BA_DENSE_H  // (-DBA_DENSE_H='"path"' -I structure_from_motion_amd/csrc: an experimental copy of the header)
+#define BA_DENSE_H "../structure_from_motion_amd/csrc/ba_dense.h"
+#endif
+#include BA_DENSE_H
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
 
