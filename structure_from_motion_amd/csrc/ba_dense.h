@@ -48,7 +48,7 @@ __global__ void k_dense_assemble(int n_upper, const long long *__restrict__ keys
 
 // x = -A^{-1} g by Cholesky; A (row-major, lower triangle used) is overwritten by its lower factor.  info = 0 or the
 // 1-based index of the first non-positive pivot (then x is not valid).  One workgroup of 8 waves, blocked right-looking:
-//   1. the 32x32 diagonal block is factored by ONE wave in LDS (two lanes per row, two columns per step, wave-level
+//   1. the 32x32 diagonal block is factored by ONE wave in LDS (two lanes per row, four columns per step, wave-level
 //      synchronisation only), overlapped with the trailing update of the column before (look-ahead),
 //   2. the panel below it: one row per lane, row <- row L_kk^-T with the inverse diagonal (no divides),
 //   3. the trailing update: every wave takes 32x32 blocks of the lower triangle as 2x2 fp64 MFMA tiles (16x16x4), operands
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(BA_DENSE_THREADS) void k_dense_cholesky_solve(int n
     // row update below reads a fixed number of entries per lane at constant offsets, some of them past the diagonal.)
     __shared__ double sLd[2][BA_NB + 1][BA_NB + 1];
     __shared__ double sInvd[2][BA_NB];           // 1 / diagonal of that block
-    __shared__ double sColL[2][2 * BA_NB];    // the two scaled columns of the block being factored (+ slack)
+    __shared__ double sColL[4][2 * BA_NB];    // the two scaled columns of the block being factored (+ slack)
     __shared__ double sY[BA_DENSE_MAX];
     __shared__ double sInvAll[BA_DENSE_MAX];     // 1 / diagonal of L, kept for the backward substitution
     __shared__ int sBad;
@@ -102,43 +102,70 @@ __global__ __launch_bounds__(BA_DENSE_THREADS) void k_dense_cholesky_solve(int n
         // TWO columns per step (the step is bound by its LDS round trips and wave syncs, not by its width): the 2x2
         // pivot block and this row's two entries in one round trip, the scaled columns to sColL (and into the block),
         // sync, then the rank-2 update of the row in ONE batch -- all loads before the FMAs -- and sync
-        auto update = [&](const int j, const double l0, const double l1, auto nt) {
+        // FOUR columns per step (the step is bound by its LDS round trips and wave syncs, not by its width): the 4x4
+        // pivot block and this row's four entries in one round trip, every lane factors the pivot block redundantly and
+        // solves its row against it, the scaled columns go to sColL (and into the block), sync, then the rank-4 update of
+        // the row in batches of NT entries -- all loads of a batch before its FMAs -- and sync
+        auto update = [&](const int j, const double (&x)[4], const int first, auto nt) {
             constexpr int NT = decltype(nt)::value;
-            // (one base address per array and constant offsets: with per-entry clamping the address arithmetic of the
-            // 45 loads cost more than the loads; entries past the diagonal are read -- inside the slack -- and dropped)
-            const double *p0 = &sColL[0][j + 2 + hi], *p1 = &sColL[1][j + 2 + hi];
-            double *rp = &sL[0][0] + r * (BA_NB + 1) + j + 2 + hi;
-            const int lim = r - (j + 2 + hi);
-            double c0[NT], c1[NT], rc[NT];
+            // (one base address per array and constant offsets; entries past the diagonal are read -- inside the slack -- and dropped)
+            const int cb = j + 4 + hi + 2 * first;
+            const double *p0 = &sColL[0][cb], *p1 = &sColL[1][cb], *p2 = &sColL[2][cb], *p3 = &sColL[3][cb];
+            double *rp = &sL[0][0] + r * (BA_NB + 1) + cb;
+            const int lim = r - cb;
+            double c0[NT], c1[NT], c2[NT], c3[NT], rc[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 c0[t] = p0[2 * t];
                 c1[t] = p1[2 * t];
+                c2[t] = p2[2 * t];
+                c3[t] = p3[2 * t];
                 rc[t] = rp[2 * t];
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-                if (2 * t <= lim) rp[2 * t] = fma(-l1, c1[t], fma(-l0, c0[t], rc[t]));
+                if (2 * t <= lim) rp[2 * t] = fma(-x[3], c3[t], fma(-x[2], c2[t], fma(-x[1], c1[t], fma(-x[0], c0[t], rc[t]))));
         };
-        for (int j = 0; j < BA_NB; j += 2) {
-            const double d00 = sL[j][j], d10 = sL[j + 1][j], d11 = sL[j + 1][j + 1], a0 = sL[r][j], a1 = sL[r][j + 1];
-            if (!(d00 > 0.0) && bad == 0) bad = k0 + j + 1;
-            const double rs0 = rsqrt_nr(d00 > 0.0 ? d00 : 1.0);
-            const double l10 = d10 * rs0, e11 = d11 - l10 * l10;
+        for (int j = 0; j < BA_NB; j += 4) {
+            const double p00 = sL[j][j], p10 = sL[j + 1][j], p11 = sL[j + 1][j + 1], p20 = sL[j + 2][j], p21 = sL[j + 2][j + 1],
+                         p22 = sL[j + 2][j + 2], p30 = sL[j + 3][j], p31 = sL[j + 3][j + 1], p32 = sL[j + 3][j + 2], p33 = sL[j + 3][j + 3];
+            const double a0 = sL[r][j], a1 = sL[r][j + 1], a2 = sL[r][j + 2], a3 = sL[r][j + 3];
+            if (!(p00 > 0.0) && bad == 0) bad = k0 + j + 1;
+            const double rs0 = rsqrt_nr(p00 > 0.0 ? p00 : 1.0);
+            const double l10 = p10 * rs0, l20 = p20 * rs0, l30 = p30 * rs0;
+            const double e11 = p11 - l10 * l10;
             if (!(e11 > 0.0) && bad == 0) bad = k0 + j + 2;
             const double rs1 = rsqrt_nr(e11 > 0.0 ? e11 : 1.0);
-            const double l0 = a0 * rs0;                                      // row j: sqrt(d00); rows above: 0
-            const double l1 = r > j ? (a1 - l0 * l10) * rs1 : 0.0;           // row j + 1: sqrt(e11); rows above: 0
+            const double l21 = (p21 - l20 * l10) * rs1, l31 = (p31 - l30 * l10) * rs1;
+            const double e22 = p22 - l20 * l20 - l21 * l21;
+            if (!(e22 > 0.0) && bad == 0) bad = k0 + j + 3;
+            const double rs2 = rsqrt_nr(e22 > 0.0 ? e22 : 1.0);
+            const double l32 = (p32 - l30 * l20 - l31 * l21) * rs2;
+            const double e33 = p33 - l30 * l30 - l31 * l31 - l32 * l32;
+            if (!(e33 > 0.0) && bad == 0) bad = k0 + j + 4;
+            const double rs3 = rsqrt_nr(e33 > 0.0 ? e33 : 1.0);
+            // this row against the pivot block (row j + k gets its diagonal entry; rows above it: 0)
+            double x[4];
+            x[0] = a0 * rs0;
+            x[1] = r > j ? (a1 - x[0] * l10) * rs1 : 0.0;
+            x[2] = r > j + 1 ? (a2 - x[0] * l20 - x[1] * l21) * rs2 : 0.0;
+            x[3] = r > j + 2 ? (a3 - x[0] * l30 - x[1] * l31 - x[2] * l32) * rs3 : 0.0;
             if (hi == 0) {
-                sColL[0][r] = l0;
-                sColL[1][r] = l1;
-                if (r >= j) sL[r][j] = l0;                // (nobody reads these two columns of the block again here)
-                if (r > j) sL[r][j + 1] = l1;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    sColL[k][r] = x[k];
+                    if (r >= j + k) sL[r][j + k] = x[k];      // (nobody reads these four columns of the block again here)
+                }
             }
             band_wave_sync();
-            // row r, columns j+2 .. r: this lane takes c = j + 2 + hi + 2 t
-            if (j < BA_NB / 2 - 2) update(j, l0, l1, std::integral_constant<int, BA_NB / 2 - 1>());
-            else update(j, l0, l1, std::integral_constant<int, BA_NB / 4>());
+            // row r, columns j+4 .. r: this lane takes c = j + 4 + hi + 2 t, t < (28 - j) / 2
+            if (j < 16) {
+                update(j, x, 0, std::integral_constant<int, 7>());
+                if (j < 12) update(j, x, 7, std::integral_constant<int, 7>());
+                else update(j, x, 7, std::integral_constant<int, 1>());
+            } else {
+                update(j, x, 0, std::integral_constant<int, 6>());
+            }
             band_wave_sync();
         }
         if (hi == 0) {
