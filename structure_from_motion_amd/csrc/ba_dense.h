@@ -194,12 +194,34 @@ __global__ __launch_bounds__(BA_DENSE_THREADS) void k_dense_cholesky_solve(int n
         const int kw = (n - k0 < BA_NB) ? n - k0 : BA_NB;
         double (&sL)[BA_NB + 1][BA_NB + 1] = sLd[kb & 1];
         double (&sInv)[BA_NB] = sInvd[kb & 1];
-        // ---- 2. panel below the diagonal block: row_i <- row_i L_kk^{-T}, one row per lane
+        // ---- 2. panel below the diagonal block: row_i <- row_i L_kk^{-T}, one row per lane.  Rows that have a place in the
+        // LDS panel travel through it in both directions: a lane reading or writing its own 256-byte row in L2 touches 64
+        // cache lines per wave instruction, the staged copies are coalesced (16 lanes per row).
+        const int prow = n - (k0 + kw), srow = prow < lds_rows ? prow : lds_rows;  // panel rows, staged panel rows
+        if (prow > 0) {  // (then kw == BA_NB: only the last block column is short, and it has no panel)
+#pragma unroll 4
+            for (int idx = tid; idx < srow * (BA_NB / 2); idx += BA_DENSE_THREADS) {
+                const int pr = idx >> 4, c = (idx & 15) * 2;
+                *reinterpret_cast<double2 *>(&sPanel[pr * BA_PS + c]) = *reinterpret_cast<const double2 *>(&A[(size_t)(k0 + kw + pr) * n + k0 + c]);
+            }
+            __syncthreads();
+        }
         for (int i = k0 + kw + tid; i < n; i += BA_DENSE_THREADS) {
             double row[BA_NB];
             double *ap = &A[(size_t)i * n + k0];
+            const int pr = i - (k0 + kw);
+            const bool staged = pr < srow;
+            if (staged) {
 #pragma unroll
-            for (int c = 0; c < BA_NB; ++c) row[c] = (c < kw) ? ap[c] : 0.0;
+                for (int c = 0; c < BA_NB; c += 2) {
+                    const double2 v = *reinterpret_cast<const double2 *>(&sPanel[pr * BA_PS + c]);
+                    row[c] = v.x;
+                    row[c + 1] = v.y;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < BA_NB; ++c) row[c] = (c < kw) ? ap[c] : 0.0;
+            }
             // Sub-blocks of eight columns: the 8x8 triangle in one LDS round trip, then the later columns lose the eight
             // solved ones four columns at a time (independent 8-FMA chains).  The empty asm makes each group's address
             // depend on the group before: left alone, the scheduler fetches all of L ahead and spills.
@@ -243,16 +265,22 @@ __global__ __launch_bounds__(BA_DENSE_THREADS) void k_dense_cholesky_solve(int n
                     asm volatile("" : "+v"(z) : "v"(row[cg + 3]));
                 }
             }
-#pragma unroll
-            for (int c = 0; c < BA_NB; ++c)
-                if (c < kw) ap[c] = row[c];
-            const int pr = i - (k0 + kw);
-            if (pr < lds_rows) {
+            if (staged) {
 #pragma unroll
                 for (int c = 0; c < BA_NB; c += 2) *reinterpret_cast<double2 *>(&sPanel[pr * BA_PS + c]) = make_double2(row[c], row[c + 1]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < BA_NB; ++c)
+                    if (c < kw) ap[c] = row[c];
             }
         }
         __syncthreads();
+        // the staged rows go back to L2 (the backward substitution reads L there); nobody waits for these stores
+#pragma unroll 4
+        for (int idx = tid; idx < srow * (BA_NB / 2); idx += BA_DENSE_THREADS) {
+            const int pr = idx >> 4, c = (idx & 15) * 2;
+            *reinterpret_cast<double2 *>(&A[(size_t)(k0 + kw + pr) * n + k0 + c]) = *reinterpret_cast<const double2 *>(&sPanel[pr * BA_PS + c]);
+        }
         BA_DT(1);
         // ---- 3. trailing update A[ib, jb] -= P_ib P_jb^T, kb < jb <= ib: one 32x32 block per wave and trip
         {
