@@ -137,6 +137,21 @@ int ba_eval_jacobian_blocks(const BaProblem *prob, double *out_jc, double *out_j
  * without observations get NaN. */
 int ba_eval_reprojection_errors(const BaProblem *prob, const double *cam_k, double *out_err);
 
+/* The one entry point that allocates nothing.  It has NO counterpart in the reference: it exists for callers that
+ * cannot allocate -- code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  It is
+ * ba_eval_cost (same kernels, same fixed-order reduction, bit-identical cost) with the library's temporaries -- the
+ * per-camera constants and the per-block partial sums -- in a static device array instead of hipMalloc'd buffers:
+ *   - every pointer of prob must be a DEVICE pointer (prob->memory == BA_MEM_DEVICE; host arrays would need staging
+ *     buffers) and so is out_cost_dev (one double);
+ *   - limits of the static array: n_cams <= 16384, n_obs <= 2^24 (16 777 216); beyond them BA_ERR_UNSUPPORTED;
+ *   - the work is only ENQUEUED on `stream` (a hipStream_t; NULL = the default stream): no hipMalloc / hipFree, no
+ *     host synchronisation; the result is in *out_cost_dev once the stream reaches that point;
+ *   - the indices are never seen by the host, so they are checked on the device: an out-of-range obs_cam / obs_pt
+ *     makes the result NaN (no fault);
+ *   - every call on one GPU uses that GPU's one static array (about 4.4 MB per GPU, held until the process ends):
+ *     calls that overlap on one GPU -- different streams or threads -- race on it.  Calls in stream order are fine. */
+int ba_eval_cost_noalloc(const BaProblem *prob, int32_t loss, double f_scale, double *out_cost_dev, void *stream);
+
 /* Host-only structure analysis (runs without a GPU). */
 int ba_analyze(const BaProblem *prob, BaAnalysis *out);
 

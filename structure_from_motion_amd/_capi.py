@@ -24,7 +24,7 @@ EXPORTED = [
     "ba_eval_jacobian_blocks", "ba_eval_reprojection_errors", "ba_analyze", "ba_create", "ba_destroy",
     "ba_get_pattern", "ba_set_pattern", "ba_set_collective", "ba_build", "ba_build_bench", "ba_run",
     "ba_get_state", "ba_get_cost", "ba_get_reduced_system", "ba_get_reduced_blocks", "ba_synchronize",
-    "ba_set_values", "ba_set_collective_mode", "ba_get_stream",
+    "ba_set_values", "ba_set_collective_mode", "ba_get_stream", "ba_eval_cost_noalloc",
 ]
 
 
@@ -93,6 +93,7 @@ def load():
     lib.ba_solve.argtypes = [P(BaProblem), P(BaOptions), P(BaSummary)]
     lib.ba_eval_residuals.argtypes = [P(BaProblem), C.c_void_p]
     lib.ba_eval_cost.argtypes = [P(BaProblem), C.c_int32, C.c_double, P(C.c_double)]
+    lib.ba_eval_cost_noalloc.argtypes = [P(BaProblem), C.c_int32, C.c_double, C.c_void_p, C.c_void_p]
     lib.ba_eval_jacobian_blocks.argtypes = [P(BaProblem), C.c_void_p, C.c_void_p]
     lib.ba_eval_reprojection_errors.argtypes = [P(BaProblem), C.c_void_p, C.c_void_p]
     lib.ba_analyze.argtypes = [P(BaProblem), P(BaAnalysis)]

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -20,6 +21,21 @@
 #include "ba_dense.h"
 #include "ba_kernels.h"
 #include "ba_heavy.h"
+
+// ---- scratch of the no-allocation entry point (ba_eval_cost_noalloc, end of this file) ------------------------------
+// A file-scope device array instead of hipMalloc'd buffers: every GPU the library runs on holds its own copy (about
+// 4.4 MB) until the process ends.  In host code the NAME below is only a stand-in, not a device address: the address
+// on the current device comes from hipGetSymbolAddress (noalloc_scratch), and only that pointer is ever handed to a
+// kernel, a memset or a copy.
+#define BA_NOALLOC_MAX_CAMS 16384
+#define BA_NOALLOC_MAX_OBS (1LL << 24)
+#define BA_NOALLOC_MAX_BLOCKS ((int)(BA_NOALLOC_MAX_OBS / 256))
+#define BA_SCR_AUX 0                                                   /* [MAX_CAMS * BA_CAM_AUX] per-camera constants */
+#define BA_SCR_BC (BA_SCR_AUX + (size_t)BA_NOALLOC_MAX_CAMS * BA_CAM_AUX) /* [MAX_BLOCKS] per-block cost partials */
+#define BA_SCR_BR (BA_SCR_BC + BA_NOALLOC_MAX_BLOCKS)                  /* [MAX_BLOCKS] per-block residual sums */
+#define BA_SCR_FLAG (BA_SCR_BR + BA_NOALLOC_MAX_BLOCKS)                /* one int: an index was out of range */
+#define BA_SCR_DOUBLES (BA_SCR_FLAG + 32)
+static __device__ __align__(256) double scratch[BA_SCR_DOUBLES];
 
 namespace {
 
@@ -629,9 +645,9 @@ int residual_sum(BaHandle *h, double *cost, double *rsum) {
     HIPCHK(bc.alloc(nb));
     HIPCHK(br.alloc(nb));
     HIPCHK(out.alloc(2));
-    hipLaunchKernelGGL(k_eval_cost, dim3(nb), dim3(256), 0, h->stream, n, h->aux[h->cur].p, h->points[h->cur].p, h->o_cam.p,
+    hipLaunchKernelGGL(k_eval_cost<false>, dim3(nb), dim3(256), 0, h->stream, n, h->aux[h->cur].p, h->points[h->cur].p, h->o_cam.p,
                        h->o_pt.p, h->o_xy.p, h->opt.loss, 1.0 / (h->opt.f_scale * h->opt.f_scale),
-                       0.5 * h->opt.f_scale * h->opt.f_scale, bc.p, br.p);
+                       0.5 * h->opt.f_scale * h->opt.f_scale, bc.p, br.p, 0, 0, (int *)nullptr);
     hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(1024), 0, h->stream, nb, 1, bc.p, out.p);
     hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(1024), 0, h->stream, nb, 1, br.p, out.p + 1);
     double host[2];
@@ -1155,8 +1171,8 @@ int ba_eval_cost(const BaProblem *p, int32_t loss, double f_scale, double *out_c
     HIPCHK(bc.alloc(nb));
     HIPCHK(br.alloc(nb));
     HIPCHK(o2.alloc(1));
-    hipLaunchKernelGGL(k_eval_cost, dim3(nb), dim3(256), 0, 0, (long long)p->n_obs, c.aux.p, c.d_points, c.d_ocam, c.d_opt,
-                       c.d_xy, loss, 1.0 / (f_scale * f_scale), 0.5 * f_scale * f_scale, bc.p, br.p);
+    hipLaunchKernelGGL(k_eval_cost<false>, dim3(nb), dim3(256), 0, 0, (long long)p->n_obs, c.aux.p, c.d_points, c.d_ocam, c.d_opt,
+                       c.d_xy, loss, 1.0 / (f_scale * f_scale), 0.5 * f_scale * f_scale, bc.p, br.p, 0, 0, (int *)nullptr);
     hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(1024), 0, 0, nb, 1, bc.p, o2.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(out_cost, o2.p, sizeof(double), hipMemcpyDeviceToHost));
@@ -1205,6 +1221,61 @@ int ba_eval_reprojection_errors(const BaProblem *p, const double *cam_k, double 
     for (size_t i = 0; i < nc; ++i) res[i] = hc[i] > 0 ? hs[i] / hc[i] : NAN;
     if (p->memory == BA_MEM_HOST) memcpy(out_err, res.data(), nc * sizeof(double));
     else HIPCHK(hipMemcpy(out_err, res.data(), nc * sizeof(double), hipMemcpyHostToDevice));
+    return BA_OK;
+}
+
+// ---- the one entry point that allocates nothing -------------------------------------------------------------------
+namespace {
+constexpr int NOALLOC_MAX_DEVICES = 64;
+std::mutex g_scratch_mu;
+double *g_scratch_ptr[NOALLOC_MAX_DEVICES] = {};
+
+// device address of `scratch` on the CURRENT device (looked up once per device, with that device current)
+int noalloc_scratch(double **out) {
+    int dev = -1;
+    HIPCHK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= NOALLOC_MAX_DEVICES) return fail(BA_ERR_UNSUPPORTED, "device ordinal %d (at most %d devices)", dev, NOALLOC_MAX_DEVICES);
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void *ptr = nullptr;
+        HIPCHK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) return fail(BA_ERR_HIP, "hipGetSymbolAddress returned a null pointer");
+        g_scratch_ptr[dev] = static_cast<double *>(ptr);
+    }
+    *out = g_scratch_ptr[dev];
+    return BA_OK;
+}
+}  // namespace
+
+int ba_eval_cost_noalloc(const BaProblem *p, int32_t loss, double f_scale, double *out_cost_dev, void *stream) {
+    int e = validate(p);
+    if (e) return e;
+    if (!out_cost_dev) return fail(BA_ERR_INVALID, "null output");
+    if (p->memory != BA_MEM_DEVICE) return fail(BA_ERR_INVALID, "ba_eval_cost_noalloc needs device-resident arrays (BA_MEM_DEVICE): staging host arrays would allocate");
+    if (loss < 0 || loss > 4 || !(f_scale > 0.0)) return fail(BA_ERR_INVALID, "bad loss / f_scale");
+    if (p->n_cams > BA_NOALLOC_MAX_CAMS || p->n_obs > BA_NOALLOC_MAX_OBS)
+        return fail(BA_ERR_UNSUPPORTED, "ba_eval_cost_noalloc: %d cameras / %lld observations exceed the static scratch (%d / %lld)",
+                    p->n_cams, (long long)p->n_obs, BA_NOALLOC_MAX_CAMS, (long long)BA_NOALLOC_MAX_OBS);
+    double *scr = nullptr;
+    if ((e = noalloc_scratch(&scr))) return e;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    double *aux = scr + BA_SCR_AUX, *bc = scr + BA_SCR_BC, *br = scr + BA_SCR_BR;
+    int *flag = reinterpret_cast<int *>(scr + BA_SCR_FLAG);
+    const int nb = (int)((p->n_obs + 255) / 256);
+    if (nb == 0) {
+        HIPCHK(hipMemsetAsync(out_cost_dev, 0, sizeof(double), st));
+        return BA_OK;
+    }
+    // the array keeps the last call's contents: the flag must start at zero; aux and the partials are overwritten
+    // for exactly the cameras / blocks this call reads
+    HIPCHK(hipMemsetAsync(flag, 0, sizeof(int), st));
+    hipLaunchKernelGGL(k_cam_prep, dim3((p->n_cams + 63) / 64), dim3(64), 0, st, p->n_cams, (const double *)p->cam_pose, p->cam_intr, aux);
+    hipLaunchKernelGGL(k_eval_cost<true>, dim3(nb), dim3(256), 0, st, (long long)p->n_obs, aux, (const double *)p->points, p->obs_cam,
+                       p->obs_pt, p->obs_xy, loss, 1.0 / (f_scale * f_scale), 0.5 * f_scale * f_scale, bc, br, p->n_cams,
+                       p->n_points, flag);
+    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(1024), 0, st, nb, 1, bc, out_cost_dev);
+    hipLaunchKernelGGL(k_nan_if, dim3(1), dim3(1), 0, st, flag, out_cost_dev);
+    HIPCHK(hipGetLastError());
     return BA_OK;
 }
 

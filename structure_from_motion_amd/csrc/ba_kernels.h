@@ -822,6 +822,10 @@ __global__ void k_reduce_max(int n, const double *__restrict__ in, double *__res
 
 __global__ void k_add_scalar(double *p, double v) { *p += v; }
 __global__ void k_copy_scalar(const double *src, double *dst) { *dst = *src; }
+// *out = NaN when *bad is set (an index was out of range), else unchanged
+__global__ void k_nan_if(const int *bad, double *out) {
+    if (*bad) *out = __longlong_as_double(0x7ff8000000000000LL);
+}
 
 // after k_build, ONE 1024-thread block: *sum_out = sum of the chunk costs (fixed order -> bitwise reproducible),
 // *max_out = max of the chunks' point-gradient maxima.  A one-block reduction is bound by load latency, so every
@@ -937,14 +941,26 @@ __global__ void k_eval_residuals(long long n_obs, const double *__restrict__ aux
     out[2 * o + 1] = v - obs_xy[2 * o + 1];
 }
 
+// CHECK (the no-allocation entry point, whose indices were never seen by the host): an observation whose camera or
+// point index is out of range is skipped and raises *bad instead of faulting; the arithmetic is the same.
+template <bool CHECK>
 __global__ void k_eval_cost(long long n_obs, const double *__restrict__ aux, const double *__restrict__ points,
                             const int *__restrict__ obs_cam, const int *__restrict__ obs_pt,
                             const double *__restrict__ obs_xy, int loss, double inv_fs2, double half_fs2,
-                            double *__restrict__ blk_cost, double *__restrict__ blk_rsum) {
+                            double *__restrict__ blk_cost, double *__restrict__ blk_rsum, int n_cams, int n_points,
+                            int *__restrict__ bad) {
     __shared__ double red[4];
     const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     double c = 0.0, rs = 0.0;
-    if (o < n_obs) {
+    bool in = o < n_obs;
+    if (CHECK && in) {
+        const int p = obs_pt[o], cm = obs_cam[o];
+        if (p < 0 || p >= n_points || cm < 0 || cm >= n_cams) {
+            *bad = 1;
+            in = false;
+        }
+    }
+    if (in) {
         const int p = obs_pt[o];
         double u, v;
         project_only(aux, obs_cam[o], points[3 * (size_t)p], points[3 * (size_t)p + 1], points[3 * (size_t)p + 2], u, v);
