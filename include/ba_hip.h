@@ -136,6 +136,11 @@ int ba_eval_jacobian_blocks(const BaProblem *prob, double *out_jc, double *out_j
  * utils.py:271-276): mean L2 error per camera with the FULL 3x3 K (cam_k[n_cams*9]); cameras
  * without observations get NaN. */
 int ba_eval_reprojection_errors(const BaProblem *prob, const double *cam_k, double *out_err);
+/* The same with the poses exactly as the reference holds them in image_data (BundleAdjustment.py:404-405): utils.py:273
+ * multiplies by the 3x3 R AS STORED, so a slightly non-orthonormal or float32-derived R (a PnP pose before any BA) must
+ * not go through R -> rvec -> R.  cam_rt[n_cams*12] = R (9, row-major), t (3) per camera; prob->cam_pose and
+ * prob->cam_intr are not read (may be NULL).  This is what compute_ba_reprojection_errors of the shim calls. */
+int ba_eval_reprojection_errors_rt(const BaProblem *prob, const double *cam_rt, const double *cam_k, double *out_err);
 
 /* The one entry point that allocates nothing.  It has NO counterpart in the reference: it exists for callers that
  * cannot allocate -- code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  It is
@@ -188,6 +193,13 @@ int ba_set_values(BaHandle *h, const BaProblem *prob, const BaOptions *opt);
 int ba_run(BaHandle *h, int32_t max_steps, BaSummary *out);
 int ba_get_state(BaHandle *h, double *cam_pose, double *points); /* host pointers, caller's order */
 int ba_get_cost(BaHandle *h, double *cost);
+/* compute_ba_reprojection_errors (BundleAdjustment.py:388-423, called right after every BA,
+ * Reconstruction.py:263) from the handle's RESIDENT state: the points and the observations stay where they are in HBM
+ * (nothing O(points) or O(observations) is marshalled or uploaded again).  Per camera, host pointers, both optional:
+ * cam_rt [n_cams*12] = R (row-major), t exactly as the caller stores them (utils.py:273 multiplies by R as stored;
+ * NULL = the handle's current poses), cam_k [n_cams*9] full K (NULL = from the handle's fx, fy, cx, cy).
+ * out_err: host, [n_cams], NaN for cameras without observations. */
+int ba_get_reprojection_errors(BaHandle *h, const double *cam_rt, const double *cam_k, double *out_err);
 /* Parity probes (host pointers, any may be NULL): dense reduced system s[(6Nf)^2] row-major,
  * g_red[6Nf], per-camera u[n_cams*36] and g_c[n_cams*6], per-point v[n_points*9] (undamped)
  * and g_p[n_points*3] of the last ba_build. */

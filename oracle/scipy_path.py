@@ -33,13 +33,15 @@ def make_closure(cam_pose, cam_intr, cam_fixed, points, obs_cam, obs_pt, obs_xy)
                     for c, p, xy in zip(obs_cam, obs_pt, obs_xy)]
     x0 = np.concatenate([cam_pose[~fixed].reshape(-1), np.asarray(points, dtype=np.float64).reshape(-1)])
     n_free = int((~fixed).sum())
+    # the reference holds R per camera and re-derives the ANCHORED cameras' rvec from it on every call (:110-114)
+    R_fixed = {c: cv2.Rodrigues(np.asarray(cam_pose[c, :3], dtype=np.float64).reshape(3, 1))[0] for c in range(n_c) if fixed[c]}
 
     def fun(params):
         idx = 0
         cam_params = {}
         for c in range(n_c):
             if fixed[c]:
-                cam_params[c] = (cam_pose[c, :3], cam_pose[c, 3:])
+                cam_params[c] = (cv2.Rodrigues(R_fixed[c])[0].flatten(), cam_pose[c, 3:])
             else:
                 cam_params[c] = (params[idx:idx + 3], params[idx + 3:idx + 6])
                 idx += 6

@@ -35,6 +35,14 @@ def _anchor_ids(cam_ids, visited_ids):
     return first, second, len(visited_ids) < 15
 
 
+def _reference_success(summary):
+    """The reference's success rule (BundleAdjustment.py:223-224): scipy's ``result.success`` (status > 0) OR the
+    quirk ``result.cost < result.fun.mean() * len(result.fun) * 0.95`` -- the cost against 0.95 x the SIGNED sum of
+    the final residuals (``BaSummary.residual_sum``).  Returns (success, converged)."""
+    converged = summary["status"] > 0
+    return converged or summary["final_cost"] < summary["residual_sum"] * 0.95, converged
+
+
 def _to_arrays(cameras, points_3d, observations, cam_ids, fixed_ids):
     """dict / list containers -> structure of arrays (the layout of ``BaProblem``)."""
     n_c = len(cam_ids)
@@ -104,10 +112,8 @@ def global_bundle_adjustment(cameras, points_3d, observations, visited_ids,
                               ftol=1e-8, xtol=1e-8, gtol=1e-8, verbose=2 if verbose else 0)
         last_summary = summary
 
-        # scipy's result.success is status > 0; the reference additionally accepts a result whose cost
-        # is below 0.95 x the signed sum of the residuals (BundleAdjustment.py:223-224).
-        converged = summary["status"] > 0
-        if converged or summary["final_cost"] < summary["residual_sum"] * 0.95:
+        success, converged = _reference_success(summary)
+        if success:
             new_cameras = {}
             R_new = rvec_to_matrix(arr.cam_pose[:, :3])
             for i, cid in enumerate(cam_ids):
@@ -246,9 +252,10 @@ def final_ba(image_data, all_points_3D, visited_ids, verbose=True):
 
 def compute_ba_reprojection_errors(image_data, all_points_3D, visited_ids):
     """Mean L2 reprojection error per registered camera, ``{img_id: error}``
-    (BundleAdjustment.py:388-423 with utils.ReprojectionError, utils.py:271-276: full K product).
+    (BundleAdjustment.py:388-423 with utils.ReprojectionError, utils.py:271-276: ``K @ (R @ X + t)`` with the full K and
+    with R exactly as stored in ``image_data`` -- no conversion to a rotation vector).
     One HIP launch for all cameras instead of one NumPy evaluation per camera."""
-    ids, poses, Ks = [], [], []
+    ids, rts, Ks = [], [], []
     obs_cam, obs_pt, obs_xy = [], [], []
     n_points = len(all_points_3D)
     for img_id in visited_ids:
@@ -263,18 +270,18 @@ def compute_ba_reprojection_errors(image_data, all_points_3D, visited_ids):
             continue
         ci = len(ids)
         ids.append(img_id)
-        poses.append(np.concatenate([matrix_to_rvec(cam_data[0]), np.asarray(cam_data[1], dtype=np.float64).reshape(3)]))
+        rts.append(np.concatenate([np.asarray(cam_data[0], dtype=np.float64).reshape(9),
+                                   np.asarray(cam_data[1], dtype=np.float64).reshape(3)]))
         Ks.append(np.asarray(cam_data[2], dtype=np.float64).reshape(9))
-        for kp_idx, point_idx in entries:
-            obs_cam.append(ci)
-            obs_pt.append(point_idx)
-            obs_xy.append(kp[kp_idx].pt)
+        kidx = np.fromiter((e[0] for e in entries), dtype=np.int64, count=len(entries))
+        obs_cam.append(np.full(len(entries), ci, dtype=np.int32))
+        obs_pt.append(np.fromiter((e[1] for e in entries), dtype=np.int32, count=len(entries)))
+        obs_xy.append(np.array([kp[k].pt for k in kidx], dtype=np.float64).reshape(-1, 2))
     if not ids:
         return {}
     points = np.array([[p[0], p[1], p[2]] for p in all_points_3D], dtype=np.float64).reshape(-1, 3)
-    Ks = np.array(Ks)
-    intr = np.stack([Ks[:, 0], Ks[:, 4], Ks[:, 2], Ks[:, 5]], axis=1)
-    arr = _capi.Arrays(np.array(poses), intr, np.zeros(len(ids), np.uint8), points, obs_cam, obs_pt,
-                       np.array(obs_xy, dtype=np.float64))
-    err = _capi.eval_reprojection_errors(arr, Ks)
+    n_c = len(ids)
+    arr = _capi.Arrays(np.zeros((n_c, 6)), np.zeros((n_c, 4)), np.zeros(n_c, np.uint8), points,
+                       np.concatenate(obs_cam), np.concatenate(obs_pt), np.concatenate(obs_xy))
+    err = _capi.eval_reprojection_errors_rt(arr, np.array(rts), np.array(Ks))
     return {img_id: float(err[i]) for i, img_id in enumerate(ids)}

@@ -25,6 +25,7 @@ EXPORTED = [
     "ba_get_pattern", "ba_set_pattern", "ba_set_collective", "ba_build", "ba_build_bench", "ba_run",
     "ba_get_state", "ba_get_cost", "ba_get_reduced_system", "ba_get_reduced_blocks", "ba_synchronize",
     "ba_set_values", "ba_set_collective_mode", "ba_get_stream", "ba_eval_cost_noalloc",
+    "ba_eval_reprojection_errors_rt", "ba_get_reprojection_errors",
 ]
 
 
@@ -96,6 +97,8 @@ def load():
     lib.ba_eval_cost_noalloc.argtypes = [P(BaProblem), C.c_int32, C.c_double, C.c_void_p, C.c_void_p]
     lib.ba_eval_jacobian_blocks.argtypes = [P(BaProblem), C.c_void_p, C.c_void_p]
     lib.ba_eval_reprojection_errors.argtypes = [P(BaProblem), C.c_void_p, C.c_void_p]
+    lib.ba_eval_reprojection_errors_rt.argtypes = [P(BaProblem), C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ba_get_reprojection_errors.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ba_analyze.argtypes = [P(BaProblem), P(BaAnalysis)]
     lib.ba_create.argtypes = [P(BaProblem), P(BaOptions)]
     lib.ba_create.restype = C.c_void_p
@@ -204,6 +207,18 @@ def eval_reprojection_errors(arr, cam_k):
     return out
 
 
+def eval_reprojection_errors_rt(arr, cam_rt, cam_k):
+    """Per-camera mean reprojection error with the poses as rotation MATRICES, used as given: cam_rt (Nc, 12) = R
+    row-major, t; cam_k (Nc, 9).  ``arr.cam_pose`` / ``arr.cam_intr`` are not read."""
+    cam_rt = np.ascontiguousarray(cam_rt, dtype=np.float64).reshape(-1, 12)
+    cam_k = np.ascontiguousarray(cam_k, dtype=np.float64).reshape(-1, 9)
+    if len(cam_rt) != arr.struct.n_cams or len(cam_k) != arr.struct.n_cams:
+        raise ValueError("cam_rt / cam_k need one row per camera")
+    out = np.empty(arr.struct.n_cams, dtype=np.float64)
+    check(load().ba_eval_reprojection_errors_rt(C.byref(arr.struct), cam_rt.ctypes.data, cam_k.ctypes.data, out.ctypes.data))
+    return out
+
+
 def analyze(arr):
     a = BaAnalysis()
     check(load().ba_analyze(C.byref(arr.struct), C.byref(a)))
@@ -278,6 +293,23 @@ class Handle:
         c = C.c_double()
         check(self._lib.ba_get_cost(self.h, C.byref(c)))
         return c.value
+
+    def reprojection_errors(self, cam_k=None, cam_rt=None):
+        """Per-camera mean reprojection error of the RESIDENT points / observations (``ba_get_reprojection_errors``);
+        cam_rt (Nc, 12) = R row-major, t as the caller holds them, or None for the handle's current poses; cam_k
+        (Nc, 9), or None for K from the handle's fx, fy, cx, cy."""
+        n = self.arr.struct.n_cams
+        out = np.empty(n, dtype=np.float64)
+        ptr = []
+        for a, w in ((cam_rt, 12), (cam_k, 9)):
+            if a is not None:
+                a = np.ascontiguousarray(a, dtype=np.float64).reshape(-1, w)
+                if len(a) != n:
+                    raise ValueError("cam_rt / cam_k need one row per camera")
+            ptr.append(a)
+        check(self._lib.ba_get_reprojection_errors(self.h, None if ptr[0] is None else ptr[0].ctypes.data,
+                                                   None if ptr[1] is None else ptr[1].ctypes.data, out.ctypes.data))
+        return out
 
     def synchronize(self):
         check(self._lib.ba_synchronize(self.h))

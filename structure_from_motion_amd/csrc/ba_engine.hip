@@ -80,10 +80,12 @@ struct DevBuf {
         if (count == 0) count = 1;
         return hipMalloc((void **)&p, count * sizeof(T));
     }
-    hipError_t upload(const std::vector<T> &v, hipStream_t s) {
+    // (a BLOCKING copy: the sources of these one-time uploads are often temporaries that die before the stream is
+    // synchronised, and HIP does not promise that a pageable-memory hipMemcpyAsync has read its source on return)
+    hipError_t upload(const std::vector<T> &v, hipStream_t) {
         hipError_t e = alloc(v.size());
         if (e != hipSuccess || v.empty()) return e;
-        return hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
+        return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
     }
     // same as upload, but keeps the allocation when the size has not changed (ba_set_values)
     hipError_t refill(const std::vector<T> &v, hipStream_t s) {
@@ -640,16 +642,21 @@ int residual_sum(BaHandle *h, double *cost, double *rsum) {
     const int nb = (int)((n + 255) / 256);
     *cost = 0.0;
     *rsum = 0.0;
-    if (nb == 0) return BA_OK;
+    if (nb == 0 && !h->coll) return BA_OK;
     DevBuf<double> bc, br, out;
     HIPCHK(bc.alloc(nb));
     HIPCHK(br.alloc(nb));
     HIPCHK(out.alloc(2));
-    hipLaunchKernelGGL(k_eval_cost<false>, dim3(nb), dim3(256), 0, h->stream, n, h->aux[h->cur].p, h->points[h->cur].p, h->o_cam.p,
+    HIPCHK(hipMemsetAsync(out.p, 0, 2 * sizeof(double), h->stream));  // (a rank without observations still joins the all-reduce)
+    if (nb > 0) hipLaunchKernelGGL(k_eval_cost<false>, dim3(nb), dim3(256), 0, h->stream, n, h->aux[h->cur].p, h->points[h->cur].p, h->o_cam.p,
                        h->o_pt.p, h->o_xy.p, h->opt.loss, 1.0 / (h->opt.f_scale * h->opt.f_scale),
                        0.5 * h->opt.f_scale * h->opt.f_scale, bc.p, br.p, 0, 0, (int *)nullptr);
-    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(1024), 0, h->stream, nb, 1, bc.p, out.p);
-    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(1024), 0, h->stream, nb, 1, br.p, out.p + 1);
+    if (nb > 0) hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(1024), 0, h->stream, nb, 1, bc.p, out.p);
+    if (nb > 0) hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(1024), 0, h->stream, nb, 1, br.p, out.p + 1);
+    // point-sharded solve: cost and residual sum of the WHOLE problem on every rank (the reference's success rule
+    // compares the two, BundleAdjustment.py:223-224; final_cost is all-reduced as well)
+    int e = call_coll(h, out.p, 2, BA_REDUCE_SUM);
+    if (e) return e;
     double host[2];
     HIPCHK(hipMemcpyAsync(host, out.p, sizeof host, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -762,25 +769,32 @@ int ba_get_pattern(BaHandle *h, int32_t *out_pairs, int64_t capacity, int64_t *n
 
 int ba_set_pattern(BaHandle *h, const int32_t *pairs, int64_t n_pairs) {
     if (!h || (n_pairs > 0 && !pairs)) return fail(BA_ERR_INVALID, "null argument");
-    std::vector<int64_t> extra;
-    extra.reserve((size_t)n_pairs);
-    for (int64_t i = 0; i < n_pairs; ++i) {
-        int a = pairs[2 * i], b = pairs[2 * i + 1];
-        if (a < 0 || b < 0 || a >= h->sym.n_free || b >= h->sym.n_free) return fail(BA_ERR_INVALID, "pattern pair out of range");
-        if (a > b) std::swap(a, b);
-        extra.push_back(((int64_t)a << 32) | (uint32_t)b);
+    if (n_pairs < 0) return fail(BA_ERR_INVALID, "negative pair count");
+    try {
+        std::vector<int64_t> extra;
+        extra.reserve((size_t)n_pairs);
+        for (int64_t i = 0; i < n_pairs; ++i) {
+            int a = pairs[2 * i], b = pairs[2 * i + 1];
+            if (a < 0 || b < 0 || a >= h->sym.n_free || b >= h->sym.n_free) return fail(BA_ERR_INVALID, "pattern pair out of range");
+            if (a > b) std::swap(a, b);
+            extra.push_back(((int64_t)a << 32) | (uint32_t)b);
+        }
+        finalize_pattern(h->sym, extra);
+        (void)hipSetDevice(h->device);
+        h->built = false;
+        return upload_pattern(h);
+    } catch (const std::bad_alloc &) {
+        return fail(BA_ERR_NOMEM, "out of host memory");
+    } catch (...) {
+        return fail(BA_ERR_INVALID, "unexpected exception in ba_set_pattern");
     }
-    finalize_pattern(h->sym, extra);
-    (void)hipSetDevice(h->device);
-    h->built = false;
-    return upload_pattern(h);
 }
 
 int ba_set_collective(BaHandle *h, BaCollectiveFn fn, void *user, int32_t rank, int32_t world) {
     if (!h) return fail(BA_ERR_INVALID, "null handle");
+    if (world > BA_MAX_WORLD || rank < 0 || (world >= 1 && rank >= world)) return fail(BA_ERR_INVALID, "rank %d of %d (at most %d ranks)", rank, world, BA_MAX_WORLD);
     h->coll = fn;
     h->coll_user = user;
-    if (world > BA_MAX_WORLD || rank < 0 || (world >= 1 && rank >= world)) return fail(BA_ERR_INVALID, "rank %d of %d (at most %d ranks)", rank, world, BA_MAX_WORLD);
     h->rank = rank;
     h->world = world < 1 ? 1 : world;
     return BA_OK;
@@ -853,7 +867,9 @@ int ba_run(BaHandle *h, int32_t max_steps, BaSummary *out) {
         printf("   Iteration     Total nfev        Cost      Cost reduction    Step norm     Optimality      lambda   pcg\n"
                "%12d %12d %16.4e %46.2e\n", 0, 1, h->hstate.F, h->hstate.gmax);
     int status = 0;
-    const int n_unknown = h->sym.n_free * 6 + h->sym.n_pts_obs * 3;
+    // (sharded solve: the point count is this rank's, and a rank that left the loop alone would leave its peers in a
+    // collective; there gmax -- all-reduced -- ends an empty problem on every rank at once)
+    const int n_unknown = h->coll ? 1 : h->sym.n_free * 6 + h->sym.n_pts_obs * 3;
     for (int step = 0; step < max_steps; ++step) {
         if (h->hstate.gmax < h->opt.gtol || n_unknown == 0) {
             status = 1;
@@ -1196,6 +1212,30 @@ int ba_eval_jacobian_blocks(const BaProblem *p, double *out_jc, double *out_jp) 
     return copy_out(out_jp, jp.p, (size_t)p->n_obs * 6, p->memory);
 }
 
+namespace {
+// shared tail of the three reprojection-error entry points: launch over (rt rows, K, points, observations) that are all
+// on the device already, per-camera means to out_err (host pointer unless out_on_device)
+int reproj_launch(hipStream_t st, int n_cams, long long n_obs, const double *rt, int stride, int t_off, const double *cam_k_dev,
+                  const double *points, const int *ocam, const int *opt, const double *xy, double *out_err, bool out_on_device) {
+    const size_t nc = (size_t)n_cams;
+    if (nc == 0) return BA_OK;
+    DevBuf<double> sum, cnt, mean;
+    HIPCHK(sum.alloc(nc));
+    HIPCHK(cnt.alloc(nc));
+    HIPCHK(mean.alloc(nc));
+    HIPCHK(hipMemsetAsync(sum.p, 0, nc * sizeof(double), st));
+    HIPCHK(hipMemsetAsync(cnt.p, 0, nc * sizeof(double), st));
+    if (n_obs)
+        hipLaunchKernelGGL(k_eval_reproj, dim3((unsigned)((n_obs + 255) / 256)), dim3(256), 0, st, n_obs, rt, stride, t_off,
+                           cam_k_dev, points, ocam, opt, xy, sum.p, cnt.p);
+    hipLaunchKernelGGL(k_mean_or_nan, dim3((n_cams + 255) / 256), dim3(256), 0, st, n_cams, sum.p, cnt.p, mean.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out_err, mean.p, nc * sizeof(double), out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return BA_OK;
+}
+}  // namespace
+
 int ba_eval_reprojection_errors(const BaProblem *p, const double *cam_k, double *out_err) {
     EvalCtx c;
     int e = eval_setup(p, c, true);
@@ -1203,25 +1243,52 @@ int ba_eval_reprojection_errors(const BaProblem *p, const double *cam_k, double 
     if (!cam_k || !out_err) return fail(BA_ERR_INVALID, "null argument");
     const size_t nc = (size_t)p->n_cams;
     if (nc == 0) return BA_OK;
-    DevBuf<double> k, sum, cnt;
+    DevBuf<double> k;
     HIPCHK(k.alloc(nc * 9));
     HIPCHK(hipMemcpy(k.p, cam_k, nc * 9 * sizeof(double), p->memory == BA_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice));
-    HIPCHK(sum.alloc(nc));
-    HIPCHK(cnt.alloc(nc));
-    HIPCHK(hipMemset(sum.p, 0, nc * sizeof(double)));
-    HIPCHK(hipMemset(cnt.p, 0, nc * sizeof(double)));
-    if (p->n_obs)
-        hipLaunchKernelGGL(k_eval_reproj, dim3((unsigned)((p->n_obs + 255) / 256)), dim3(256), 0, 0, (long long)p->n_obs,
-                           c.aux.p, k.p, c.d_points, c.d_ocam, c.d_opt, c.d_xy, sum.p, cnt.p);
-    HIPCHK(hipGetLastError());
-    std::vector<double> hs(nc), hc(nc);
-    HIPCHK(hipMemcpy(hs.data(), sum.p, nc * sizeof(double), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(hc.data(), cnt.p, nc * sizeof(double), hipMemcpyDeviceToHost));
-    std::vector<double> res(nc);
-    for (size_t i = 0; i < nc; ++i) res[i] = hc[i] > 0 ? hs[i] / hc[i] : NAN;
-    if (p->memory == BA_MEM_HOST) memcpy(out_err, res.data(), nc * sizeof(double));
-    else HIPCHK(hipMemcpy(out_err, res.data(), nc * sizeof(double), hipMemcpyHostToDevice));
-    return BA_OK;
+    return reproj_launch(0, p->n_cams, (long long)p->n_obs, c.aux.p, BA_CAM_AUX, 18, k.p, c.d_points, c.d_ocam, c.d_opt, c.d_xy,
+                         out_err, p->memory != BA_MEM_HOST);
+}
+
+int ba_eval_reprojection_errors_rt(const BaProblem *p, const double *cam_rt, const double *cam_k, double *out_err) {
+    if (!p || !cam_rt || !cam_k || !out_err) return fail(BA_ERR_INVALID, "null argument");
+    BaProblem q = *p;
+    q.cam_pose = const_cast<double *>(cam_rt);  // (only so that the shared set-up finds a pose array; the rvec-derived rows are not used)
+    // (cam_intr is not used either, but the shared set-up wants the pointer)
+    if (!q.cam_intr) q.cam_intr = cam_k;
+    EvalCtx c;
+    int e = eval_setup(&q, c, true);
+    if (e) return e;
+    const size_t nc = (size_t)p->n_cams;
+    if (nc == 0) return BA_OK;
+    const hipMemcpyKind kind = p->memory == BA_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    DevBuf<double> k, rt;
+    HIPCHK(k.alloc(nc * 9));
+    HIPCHK(rt.alloc(nc * 12));
+    HIPCHK(hipMemcpy(k.p, cam_k, nc * 9 * sizeof(double), kind));
+    HIPCHK(hipMemcpy(rt.p, cam_rt, nc * 12 * sizeof(double), kind));
+    return reproj_launch(0, p->n_cams, (long long)p->n_obs, rt.p, 12, 9, k.p, c.d_points, c.d_ocam, c.d_opt, c.d_xy, out_err,
+                         p->memory != BA_MEM_HOST);
+}
+
+int ba_get_reprojection_errors(BaHandle *h, const double *cam_rt, const double *cam_k, double *out_err) {
+    if (!h || !out_err) return fail(BA_ERR_INVALID, "null argument");
+    (void)hipSetDevice(h->device);
+    const Symbolic &s = h->sym;
+    const size_t nc = (size_t)s.n_cams;
+    if (nc == 0) return BA_OK;
+    DevBuf<double> k, rt;
+    HIPCHK(k.alloc(nc * 9));
+    if (cam_k) HIPCHK(hipMemcpyAsync(k.p, cam_k, nc * 9 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    else hipLaunchKernelGGL(k_intr_to_k, dim3((s.n_cams + 63) / 64), dim3(64), 0, h->stream, s.n_cams, h->intr.p, k.p);
+    if (cam_rt) {
+        HIPCHK(rt.alloc(nc * 12));
+        HIPCHK(hipMemcpyAsync(rt.p, cam_rt, nc * 12 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
+    // resident state: points and observations in the engine's order (a per-camera mean does not depend on the order),
+    // and -- unless the caller hands the matrices over -- the current poses' aux rows (R = Rodrigues(rvec), t)
+    return reproj_launch(h->stream, s.n_cams, (long long)s.n_obs, cam_rt ? rt.p : h->aux[h->cur].p, cam_rt ? 12 : BA_CAM_AUX,
+                         cam_rt ? 9 : 18, k.p, h->points[h->cur].p, h->o_cam.p, h->o_pt.p, h->o_xy.p, out_err, false);
 }
 
 // ---- the one entry point that allocates nothing -------------------------------------------------------------------

@@ -995,19 +995,22 @@ __global__ void k_eval_jacobian(long long n_obs, const double *__restrict__ aux,
     }
 }
 
-// per-camera mean L2 reprojection error with the full K (utils.py:271-276): sums by atomics
-__global__ void k_eval_reproj(long long n_obs, const double *__restrict__ aux, const double *__restrict__ cam_k,
+// per-camera mean L2 reprojection error with the full K (utils.py:271-276): sums by atomics.  The pose comes from
+// rows of `rt` (stride doubles per camera, R row-major at 0, t at t_off): the engine's aux rows (stride BA_CAM_AUX,
+// t at 18) or rotation matrices exactly as the caller holds them (stride 12, t at 9).
+__global__ void k_eval_reproj(long long n_obs, const double *__restrict__ rt, int stride, int t_off,
+                              const double *__restrict__ cam_k,
                               const double *__restrict__ points, const int *__restrict__ obs_cam,
                               const int *__restrict__ obs_pt, const double *__restrict__ obs_xy,
                               double *__restrict__ cam_sum, double *__restrict__ cam_cnt) {
     const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= n_obs) return;
     const int p = obs_pt[o], c = obs_cam[o];
-    const double *a = aux + (size_t)c * BA_CAM_AUX;
+    const double *a = rt + (size_t)c * stride, *tt = a + t_off;
     const double X0 = points[3 * (size_t)p], X1 = points[3 * (size_t)p + 1], X2 = points[3 * (size_t)p + 2];
-    const double x = a[0] * X0 + a[1] * X1 + a[2] * X2 + a[18];
-    const double y = a[3] * X0 + a[4] * X1 + a[5] * X2 + a[19];
-    const double z = a[6] * X0 + a[7] * X1 + a[8] * X2 + a[20];
+    const double x = a[0] * X0 + a[1] * X1 + a[2] * X2 + tt[0];
+    const double y = a[3] * X0 + a[4] * X1 + a[5] * X2 + tt[1];
+    const double z = a[6] * X0 + a[7] * X1 + a[8] * X2 + tt[2];
     const double *K = cam_k + 9 * (size_t)c;
     const double h0 = K[0] * x + K[1] * y + K[2] * z;
     const double h1 = K[3] * x + K[4] * y + K[5] * z;
@@ -1015,6 +1018,21 @@ __global__ void k_eval_reproj(long long n_obs, const double *__restrict__ aux, c
     const double e0 = obs_xy[2 * o] - h0 / h2, e1 = obs_xy[2 * o + 1] - h1 / h2;
     atomicAdd(&cam_sum[c], sqrt(e0 * e0 + e1 * e1));
     atomicAdd(&cam_cnt[c], 1.0);
+}
+
+// K = [[fx 0 cx] [0 fy cy] [0 0 1]] per camera from the engine's (fx, fy, cx, cy)
+__global__ void k_intr_to_k(int n_cams, const double *__restrict__ intr, double *__restrict__ cam_k) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cams) return;
+    double *K = cam_k + 9 * (size_t)c;
+    const double *in = intr + 4 * (size_t)c;
+    K[0] = in[0]; K[1] = 0.0; K[2] = in[2];
+    K[3] = 0.0; K[4] = in[1]; K[5] = in[3];
+    K[6] = 0.0; K[7] = 0.0; K[8] = 1.0;
+}
+__global__ void k_mean_or_nan(int n, const double *__restrict__ sum, const double *__restrict__ cnt, double *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = cnt[i] > 0.0 ? sum[i] / cnt[i] : __longlong_as_double(0x7ff8000000000000LL);
 }
 
 }  // namespace ba

@@ -23,13 +23,16 @@ from .geometry import matrix_to_rvec, rvec_to_matrix
 
 class BASession:
     def __init__(self, reuse_device=True):
-        self._kp_xy = {}          # img_id -> (id of the keypoint list, its length, (k, 2) float64 coordinates)
+        self._kp_xy = {}          # img_id -> (the keypoint list, its length, (k, 2) float64 coordinates)
         self.last_summary = None
         self.reuse_device = reuse_device
         self._handle = None       # engine handle of the last solve (structure + device buffers)
         self.handle_reuses = 0
+        self._resident = None     # what the handle's device state corresponds to on the host (see compute_ba_reprojection_errors)
+        self.resident_error_calls = 0
 
     def close(self):
+        self._resident = None
         if self._handle is not None:
             self._handle.close()
             self._handle = None
@@ -67,12 +70,25 @@ class BASession:
 
     # ------------------------------------------------------------------ marshalling
     def _keypoints(self, img_id, kp):
+        # The cache entry holds the keypoint LIST ITSELF and is valid for that very object only (`is`: an id() could be
+        # recycled by a new list of the same length).  The first and last coordinates are re-checked as a cheap guard
+        # against in-place edits; an edit in the middle of a list needs `invalidate(img_id)`.
         hit = self._kp_xy.get(img_id)
-        if hit is not None and hit[0] == id(kp) and hit[1] == len(kp):
-            return hit[2]
+        if hit is not None and hit[0] is kp and hit[1] == len(kp):
+            xy = hit[2]
+            if len(kp) == 0 or (tuple(xy[0]) == tuple(map(float, kp[0].pt)) and tuple(xy[-1]) == tuple(map(float, kp[-1].pt))):
+                return xy
         xy = np.array([k.pt for k in kp], dtype=np.float64).reshape(-1, 2)
-        self._kp_xy[img_id] = (id(kp), len(kp), xy)
+        self._kp_xy[img_id] = (kp, len(kp), xy)
         return xy
+
+    def invalidate(self, img_id=None):
+        """Forget the cached keypoint coordinates of one image (or of all): needed after editing ``kp[k].pt`` in place."""
+        self._resident = None
+        if img_id is None:
+            self._kp_xy.clear()
+        else:
+            self._kp_xy.pop(img_id, None)
 
     def _track_entries(self, img_id, cam_data, n_points):
         """(keypoint indices, point indices) of one image under the reference's rules (:260-264)."""
@@ -135,13 +151,14 @@ class BASession:
         fixed_ids = {first_id, second_id} if anchor_second else {first_id}
         for i, cid in enumerate(cam_ids):
             arr.cam_fixed[i] = cid in fixed_ids
+        self._resident = None
         try:
             if n_o and (arr.obs_pt.min() < 0 or arr.obs_pt.max() >= n_p):
                 raise KeyError(int(arr.obs_pt.max()))
             s = self._run(arr, loss="huber", f_scale=float(f_scale), max_iter=int(max_nfev),
                           ftol=1e-8, xtol=1e-8, gtol=1e-8, verbose=2 if verbose else 0)
             self.last_summary = _ba.last_summary = s
-            if not (s["status"] > 0 or s["final_cost"] < s["residual_sum"] * 0.95):
+            if not _ba._reference_success(s)[0]:
                 if verbose:
                     print(f"[BA] Bundle adjustment failed: status {s['status']} after {s['iterations']} steps")
                 return all_points_3D, image_data, False
@@ -158,6 +175,13 @@ class BASession:
                 new_points = np.concatenate([arr.points, colours], axis=1).tolist()
             else:
                 new_points = [[x, y, z] + list(p[3:6]) for (x, y, z), p in zip(arr.points.tolist(), all_points_3D)]
+            if self._handle is not None:
+                # the handle's device state IS what was just written back: remember the very objects, so that a
+                # following compute_ba_reprojection_errors can tell that nothing was replaced in between
+                self._resident = dict(cam_ids=list(cam_ids), points=new_points, n_points=len(new_points),
+                                      R={c: image_data[c][0] for c in cam_ids}, t={c: image_data[c][1] for c in cam_ids},
+                                      ref={c: (image_data[c][3], len(image_data[c][3])) for c in cam_ids},
+                                      kp={c: (image_data[c][5], len(image_data[c][5])) for c in cam_ids})
             return new_points, image_data, True
         except Exception as e:                        # as the reference: any failure -> (inputs, False) (:238-240)
             print(f"[BA] Bundle adjustment error: {e}")
@@ -172,6 +196,29 @@ class BASession:
     def final_ba(self, image_data, all_points_3D, visited_ids, verbose=True):
         """As ``final_ba`` (``BundleAdjustment.py:353-385``): huber, f_scale 1.0, max_nfev 300."""
         return self._solve(image_data, all_points_3D, visited_ids, 1.0, 300, verbose, min_obs=0)
+
+    def compute_ba_reprojection_errors(self, image_data, all_points_3D, visited_ids):
+        """As ``compute_ba_reprojection_errors`` (``BundleAdjustment.py:388-423``), which the reference's driver calls
+        right after every successful BA (``Reconstruction.py:263``) -- SURVEY.md 8(f) f2: when the arguments are exactly
+        what the last solve of this session returned (same point list object and length, same R / t / reference /
+        keypoint objects per image), the errors come from the handle's RESIDENT state: one kernel over the observations
+        already in HBM, nothing re-marshalled, only the 21 camera numbers (R, t, K) per image uploaded.  Anything else (no handle, other images, a
+        grown point list) takes the module function's path.  In-place edits of a kept object are not detected --
+        ``invalidate()`` / ``close()`` after such edits."""
+        r = self._resident
+        if r is not None and self._handle is not None and all_points_3D is r["points"] and len(all_points_3D) == r["n_points"]:
+            usable = list(dict.fromkeys(i for i in visited_ids if i in image_data and len(image_data[i]) >= 6))
+            if usable == r["cam_ids"] and all(
+                    image_data[c][0] is r["R"][c] and image_data[c][1] is r["t"][c]
+                    and image_data[c][3] is r["ref"][c][0] and len(image_data[c][3]) == r["ref"][c][1]
+                    and image_data[c][5] is r["kp"][c][0] and len(image_data[c][5]) == r["kp"][c][1] for c in usable):
+                Ks = np.array([np.asarray(image_data[c][2], dtype=np.float64).reshape(9) for c in usable])
+                Rt = np.array([np.concatenate([np.asarray(image_data[c][0], dtype=np.float64).reshape(9),
+                                               np.asarray(image_data[c][1], dtype=np.float64).reshape(3)]) for c in usable])
+                err = self._handle.reprojection_errors(Ks, Rt)
+                self.resident_error_calls += 1
+                return {cid: float(err[i]) for i, cid in enumerate(usable) if not np.isnan(err[i])}
+        return _ba.compute_ba_reprojection_errors(image_data, all_points_3D, visited_ids)
 
     # ------------------------------------------------------------------ opt-in step next to the path (8(f) f4)
     def cull_points(self, image_data, all_points_3D, visited_ids, max_error_px, min_track=1):
@@ -190,6 +237,7 @@ class BASession:
         track = np.bincount(arr.obs_pt, minlength=n_p)
         bad = np.flatnonzero((track > 0) & ((worst > max_error_px) | (track < min_track)))
         if len(bad):
+            self._resident = None                    # (the reference arrays are edited in place below)
             is_bad = np.zeros(n_p, dtype=bool)
             is_bad[bad] = True
             for cid in cam_ids:

@@ -176,6 +176,15 @@ def make_config(name, seed=None, scale=1.0):
         return make_ring(11, int(16908 * scale), seed=1235 if seed is None else seed,
                          K=(2759.48 * 1600 / 3072, 2764.16 * 1600 / 3072, 1520.69 * 1600 / 3072, 1006.81 * 1600 / 3072),
                          focal_jitter=0.0, noise=0.4, mean_track=3.5, n_fixed=2)
+    if name == "fountain_sfm":
+        # the visibility Reconstruction.py really records: the seed pair's points are seen twice
+        # (cameras 0 and 1, both anchored below 15 images), every later point once, by the image that triangulated it
+        return make_ring(11, int(16908 * scale), seed=1237 if seed is None else seed,
+                         K=(2759.48 * 1600 / 3072, 2764.16 * 1600 / 3072, 1520.69 * 1600 / 3072, 1006.81 * 1600 / 3072),
+                         focal_jitter=0.0, noise=0.4, visibility="sfm", n_seed_points=int(2500 * scale), n_fixed=2)
+    if name == "temple_sfm":
+        return make_ring(47, int(20467 * scale), seed=1238 if seed is None else seed, focal_jitter=0.02, noise=0.35,
+                         visibility="sfm", n_seed_points=int(1500 * scale), n_fixed=1)
     if name in ("temple", "C2"):
         return make_ring(47, int(20467 * scale), seed=1236 if seed is None else seed, focal_jitter=0.02,
                          noise=0.35, mean_track=4.0, n_fixed=1)

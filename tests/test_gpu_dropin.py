@@ -91,6 +91,108 @@ def test_global_ba_containers_and_gauge(gpu):
     assert BA.last_summary["status"] > 0
 
 
+def test_success_quirk_branch_is_reached(gpu, monkeypatch):
+    """a7, the branch scipy alone never takes: status == 0 (max_nfev spent) but cost < 0.95 x the SIGNED residual sum
+    (BundleAdjustment.py:223-224) -> the reference returns the new containers with True.  Every observed pixel is
+    moved so that all residuals start near +4 px (Huber's linear zone: cost ~ sum(f - 0.5) < 0.95 sum f), and the
+    damping starts high (lambda0 = 30: about 3 % of the Gauss-Newton step) so the single allowed step stays there."""
+    from structure_from_motion_amd import _capi
+    g = load_golden("ring16_dense")
+    ids = [int(v) for v in g["cam_ids"]]
+    R = O.rodrigues(g["cam_pose"][:, :3])
+    cams = {cid: {"R": R[i].copy(), "t": g["cam_pose"][i, 3:].reshape(3, 1).copy(),
+                  "K": np.array([[g["cam_intr"][i, 0], 0, g["cam_intr"][i, 2]], [0, g["cam_intr"][i, 1], g["cam_intr"][i, 3]], [0, 0, 1.0]])}
+            for i, cid in enumerate(ids)}
+    pts = [[*map(float, p), 0.5, 0.5, 0.5] for p in g["points"]]
+    proj = O.residuals(g["cam_pose"], g["cam_intr"], g["points"], g["obs_cam"], g["obs_pt"], np.zeros_like(g["obs_xy"])).reshape(-1, 2)
+    obs = [{"camera_id": ids[int(c)], "point_idx": int(p), "pixel": xy - 4.0}
+           for c, p, xy in zip(g["obs_cam"], g["obs_pt"], proj)]
+    visited = [int(v) for v in g["visited_ids"]]
+    real_defaults = _capi.default_options
+    monkeypatch.setattr(_capi, "default_options", lambda **kw: real_defaults(**{**kw, "lambda0": 30.0}))
+    new_c, new_p, ok = BA.global_bundle_adjustment(cams, pts, obs, visited, robust_loss="huber", loss_f_scale=1.0,
+                                                   max_nfev=1, verbose=1)
+    s = BA.last_summary
+    assert s["status"] == 0 and s["iterations"] == 1
+    assert s["final_cost"] < 0.95 * s["residual_sum"]                     # the quirk's condition holds ...
+    assert ok is True and new_c is not cams and new_p is not pts           # ... and is honoured
+    assert BA._reference_success(s) == (True, False)
+    # without the quirk's condition a status-0 result is refused and the ORIGINAL objects come back
+    obs2 = [{"camera_id": o["camera_id"], "point_idx": o["point_idx"], "pixel": o["pixel"] + 8.0} for o in obs]   # all residuals near -4
+    out = BA.global_bundle_adjustment(cams, pts, obs2, visited, robust_loss="huber", loss_f_scale=1.0, max_nfev=1, verbose=0)
+    assert BA.last_summary["status"] == 0 and BA.last_summary["residual_sum"] < 0
+    assert out[2] is False and out[0] is cams and out[1] is pts
+
+
+def _reference_errors(image_data, pts, ids):
+    """utils.ReprojectionError (utils.py:271-276) as compute_ba_reprojection_errors applies it (:388-423)."""
+    return _errors(image_data, pts, ids)
+
+
+def test_reprojection_errors_use_R_as_stored(gpu):
+    """a13: the reference multiplies by the 3x3 R exactly as image_data holds it (utils.py:273).  A float32-derived R, a
+    slightly non-orthonormal R (a PnP pose before any BA) and a rotation below 1e-5 rad (which cv2.Rodrigues would turn
+    into the zero vector) must all give the reference formula's numbers -- no R -> rvec -> R round trip."""
+    g = load_golden("marshalling")
+    ids, image_data, pts = _image_data_from_golden(g)
+    rng = np.random.default_rng(3)
+    e = list(image_data[ids[0]]); e[0] = e[0].astype(np.float32).astype(np.float64); image_data[ids[0]] = tuple(e)
+    e = list(image_data[ids[1]]); e[0] = e[0] + 1e-3 * rng.normal(size=(3, 3)); image_data[ids[1]] = tuple(e)
+    e = list(image_data[ids[2]]); e[0] = O.rodrigues(np.array([4e-6, -3e-6, 2e-6])); e[1] = np.array([[0.01], [0.0], [4.0]])
+    image_data[ids[2]] = tuple(e)
+    e = list(image_data[ids[3]]); e[0] = e[0].astype(np.float32); e[1] = e[1].astype(np.float32); image_data[ids[3]] = tuple(e)  # float32 containers
+    want = _reference_errors(image_data, pts, ids)
+    got = BA.compute_ba_reprojection_errors(image_data, pts, ids)
+    assert list(got.keys()) == ids
+    for cid in ids:
+        assert abs(got[cid] - want[cid]) <= 1e-9 * max(1.0, want[cid]), cid
+    # the rvec round trip the reference does NOT do would be visibly off for the perturbed cameras
+    from structure_from_motion_amd.geometry import rvec_to_matrix
+    d2 = copy.deepcopy(image_data)
+    for cid in ids[:3]:
+        e = list(d2[cid]); e[0] = rvec_to_matrix(matrix_to_rvec(e[0])); d2[cid] = tuple(e)
+    off = _reference_errors(d2, pts, ids)
+    assert max(abs(off[c] - want[c]) for c in ids[:3]) > 1e-4
+    # a camera without valid references is left out, like the reference's `continue` (:413-414)
+    e = list(image_data[ids[4]]); e[3] = [-1] * len(e[3]); image_data[ids[4]] = tuple(e)
+    got = BA.compute_ba_reprojection_errors(image_data, pts, ids)
+    assert ids[4] not in got and len(got) == len(ids) - 1
+
+
+def test_resident_reprojection_errors_after_ba(gpu):
+    """f2: right after a BA the session answers compute_ba_reprojection_errors from the handle's resident points and
+    observations (Reconstruction.py:263 calls it after every BA); same numbers as the reference formula on the returned
+    containers, and as the C-ABI probe with the handle's own poses."""
+    from structure_from_motion_amd.session import BASession
+    g = load_golden("marshalling")
+    ids, image_data, pts = _image_data_from_golden(g)
+    e = list(image_data[ids[0]]); e[0] = e[0] + 2e-4 * np.random.default_rng(1).normal(size=(3, 3)); image_data[ids[0]] = tuple(e)  # anchored, not quite orthonormal
+    sess = BASession()
+    p2, d2, ok = sess.final_ba(image_data, pts, ids, verbose=False)
+    assert ok is True
+    got = sess.compute_ba_reprojection_errors(d2, p2, ids)
+    assert sess.resident_error_calls == 1                                  # the resident path ran
+    want = _reference_errors(d2, p2, ids)
+    assert list(got.keys()) == ids
+    for cid in ids:
+        assert abs(got[cid] - want[cid]) <= 1e-9 * max(1.0, want[cid])
+    stateless = BA.compute_ba_reprojection_errors(d2, p2, ids)
+    assert all(abs(stateless[c] - got[c]) <= 1e-9 for c in ids)
+    # handle-level probe with the resident poses and the engine's own intrinsics: the free cameras agree with the above
+    # (the anchored camera's stored R is not orthonormal; the engine holds its nearest rotation)
+    err = sess._handle.reprojection_errors()
+    for i, cid in enumerate(ids[2:], start=2):
+        assert abs(err[i] - want[cid]) <= 1e-6
+    # anything that is not the returned state falls back to the stateless path: a grown point list, another image set
+    p3 = list(p2) + [[0.0, 0.0, 5.0, 0, 0, 0]]
+    sess.compute_ba_reprojection_errors(d2, p3, ids)
+    sess.compute_ba_reprojection_errors(d2, p2, ids[:4])
+    e = list(d2[ids[3]]); e[0] = e[0].copy(); d2[ids[3]] = tuple(e)        # a replaced R object
+    sess.compute_ba_reprojection_errors(d2, p2, ids)
+    assert sess.resident_error_calls == 1
+    sess.close()
+
+
 def test_session_path_equals_module_functions(gpu):
     """BASession.final_ba / inter_ba return what the module functions return."""
     from structure_from_motion_amd.session import BASession

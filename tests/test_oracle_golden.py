@@ -99,6 +99,27 @@ def test_temple_shaped_fixture_pins_oracle():
     assert abs(O.cost(fr, float(g["f_scale"]), "huber") - float(g["ref_cost"])) <= 1e-10 * float(g["ref_cost"])
 
 
+@pytest.mark.parametrize("name", ["temple_final", "fountain_final", "fountain_final_sfm", "temple_final_sfm"])
+def test_config_size_fixtures_pin_oracle(name):
+    """BASELINE configs 0 / 1 at full size (make_golden.py --config-size): the reference's x0 and its closure's f(x0),
+    and the reference-closure cost at the stored minimiser, against the oracle."""
+    g = load_golden(name)
+    p = problem_of(g)
+    np.testing.assert_allclose(O.pack(p["cam_pose"], p["cam_fixed"], p["points"]), g["x0"], rtol=0, atol=1e-12)
+    f = O.residuals(p["cam_pose"], p["cam_intr"], p["points"], p["obs_cam"], p["obs_pt"], p["obs_xy"])
+    np.testing.assert_allclose(f, g["f0"], rtol=1e-8, atol=1e-9)
+    assert np.linalg.norm(f - g["f0"]) <= 1e-10 * np.linalg.norm(g["f0"])
+    fs = float(g["f_scale"])
+    assert abs(O.cost(f, fs, "huber") - float(g["cost0"])) <= 1e-11 * float(g["cost0"])
+    cp, pt = O.unpack(g["tight_x"], p["cam_pose"], p["cam_fixed"], len(p["points"]))
+    ft = O.residuals(cp, p["cam_intr"], pt, p["obs_cam"], p["obs_pt"], p["obs_xy"])
+    c = O.cost(ft, fs, "huber")
+    assert abs(c - float(g["tight_cost"])) <= 1e-11 * c
+    assert float(g["tight_grad_inf"]) < 1e-4 and int(g["tight_status"]) > 0
+    if name.endswith("_sfm"):        # SURVEY.md H4: tracks of 2 (seed points) and 1 (everything else)
+        assert set(np.bincount(p["obs_pt"])) <= {1, 2}
+
+
 def test_matrix_free_schur_product_equals_dense():
     g = load_golden("ring_unobserved")
     p = problem_of(g)
