@@ -74,6 +74,26 @@ __device__ __forceinline__ void load_aux(const double *__restrict__ aux, int cam
     c.fx = v[10].y; c.fy = v[11].x; c.cx = v[11].y; c.cy = v[12].x;
 }
 
+// The same without the left Jacobian (Jl = I): the BUILD kernels linearise in the local tangent of the rotation,
+// d(R X)/d omega = -[R X]x, and the reduced system is brought to the rvec parameters once per build pass by
+// k_apply_jl (S = D^T S' D with D = diag(Jl, I) per camera) instead of once per observation.  In these coordinates the
+// camera block of an observation is Jc' = P [-[Y]x | I] (Y = R X), which is what lets k_build keep only a 3x3 block
+// and Y per observation in LDS (see its phase 2b / 3).
+__device__ __forceinline__ void load_aux_local(const double *__restrict__ aux, int cam, CamAux &c) {
+    const double2 *p = reinterpret_cast<const double2 *>(aux + (size_t)cam * BA_CAM_AUX);
+    double2 v[13];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) v[i] = p[i];
+#pragma unroll
+    for (int i = 9; i < 13; ++i) v[i] = p[i];
+    c.R[0] = v[0].x; c.R[1] = v[0].y; c.R[2] = v[1].x; c.R[3] = v[1].y; c.R[4] = v[2].x; c.R[5] = v[2].y;
+    c.R[6] = v[3].x; c.R[7] = v[3].y; c.R[8] = v[4].x;
+    c.Jl[0] = 1.0; c.Jl[1] = 0.0; c.Jl[2] = 0.0; c.Jl[3] = 0.0; c.Jl[4] = 1.0; c.Jl[5] = 0.0;
+    c.Jl[6] = 0.0; c.Jl[7] = 0.0; c.Jl[8] = 1.0;
+    c.t[0] = v[9].x; c.t[1] = v[9].y; c.t[2] = v[10].x;
+    c.fx = v[10].y; c.fy = v[11].x; c.cx = v[11].y; c.cy = v[12].x;
+}
+
 // Projection only (trial-cost and evaluation kernels): R, t, intrinsics.
 __device__ __forceinline__ void project_only(const double *__restrict__ aux, int cam, double X0, double X1, double X2,
                                              double &u, double &v) {
@@ -124,6 +144,7 @@ struct ObsLin {
     double rho_sum;   // rho(z_u) + rho(z_v)
     double Jc[2][6];  // d(du,dv)/d(rvec, t)
     double Jp[2][3];  // d(du,dv)/dX
+    double Y[3];      // R X (the rotated point, before the translation)
 };
 
 // Residual + analytic Jacobian blocks of one observation.
@@ -133,6 +154,7 @@ __device__ __forceinline__ void linearize(const CamAux &c, double X0, double X1,
     const double Y1 = c.R[3] * X0 + c.R[4] * X1 + c.R[5] * X2;
     const double Y2 = c.R[6] * X0 + c.R[7] * X1 + c.R[8] * X2;
     const double x = Y0 + c.t[0], y = Y1 + c.t[1], z = Y2 + c.t[2];
+    o.Y[0] = Y0; o.Y[1] = Y1; o.Y[2] = Y2;
     const bool nz = (z != 0.0);
     const double iz = nz ? 1.0 / z : 1.0;
     const double xn = x * iz, yn = y * iz;
@@ -162,6 +184,17 @@ __device__ __forceinline__ void linearize(const CamAux &c, double X0, double X1,
     o.wh[0] = fmax(c0, curv_floor * o.w[0]);
     o.wh[1] = fmax(c1, curv_floor * o.w[1]);
     o.rho_sum = rho0 + rho1;
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope fence over ALL address
+// spaces, so hipcc puts s_waitcnt vmcnt(0) in front of every s_barrier: each barrier then also waits for the
+// workgroup's global loads, stores and atomics to complete (a store acknowledgement is hundreds of cycles).  With the
+// fence restricted to the local address space only lgkmcnt is drained; global traffic stays in flight across it.
+// Use it wherever the data handed across the barrier lives in LDS (all barriers of the chunk kernels do).
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 // index of (i,j), i<=j, in a row-major packed upper triangle of a 6x6

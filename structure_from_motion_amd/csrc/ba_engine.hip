@@ -158,7 +158,7 @@ struct BaHandle {
     DevBuf<double> pose[2], aux[2], points[2];
     int cur = 0;
     DevBuf<double> intr;
-    DevBuf<int> cam_free;
+    DevBuf<int> cam_free, free_cam;
     // observations, chunks
     DevBuf<int> o_cam, o_pt, ck_obs, ck_pt, ck_cam, ck_cam_list, ck_pair, ck_pair_slot;
     DevBuf<short> o_lcam;
@@ -295,9 +295,12 @@ int do_build(BaHandle *h, bool timed) {
         BuildArgs A = build_args(h);
         if (h->stamps.n) {
             A.stamps = h->stamps.p;
-            hipLaunchKernelGGL(k_build<true>, dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, A);
+            if (h->opt.loss == BA_LOSS_HUBER) hipLaunchKernelGGL((k_build<true, BA_LOSS_HUBER>), dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, A);
+            else hipLaunchKernelGGL((k_build<true, -1>), dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, A);
+        } else if (h->opt.loss == BA_LOSS_HUBER) {
+            hipLaunchKernelGGL((k_build<false, BA_LOSS_HUBER>), dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, A);
         } else {
-            hipLaunchKernelGGL(k_build<false>, dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, A);
+            hipLaunchKernelGGL((k_build<false, -1>), dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, A);
         }
     }
     if (timed) HIPCHK(hipEventRecord(h->ev1, st));
@@ -311,6 +314,9 @@ int do_build(BaHandle *h, bool timed) {
         if (e) return e;
         hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(256), 0, st, h->world, h->red.p + nred, h->gm2.p);
     }
+    if (nf > 0)  // (after the all-reduce: the transform is linear, and every rank holds the same cameras)
+        hipLaunchKernelGGL(k_apply_jl, dim3((h->n_upper + nf + 127) / 128), dim3(128), 0, st, nf, h->n_upper, h->upper_keys.p,
+                           h->free_cam.p, h->aux[h->cur].p, h->S, h->U, h->gc, h->gred);
     if (nf > 0)
         hipLaunchKernelGGL(k_finalize, dim3((nf + 63) / 64), dim3(64), 0, st, nf, h->U, h->gc, h->gred, h->S, h->diag_slot.p,
                            h->Minv.p, h->cam_gmax.p, h->state.p);
@@ -579,6 +585,7 @@ int create_impl(const BaProblem *prob, const BaOptions *opt, BaHandle *h) {
     }
     for (int b = 0; b < 2; ++b) HIPCHK(h->aux[b].alloc((size_t)s.n_cams * BA_CAM_AUX));
     HIPCHK(h->cam_free.upload(s.cam_free, st));
+    HIPCHK(h->free_cam.upload(s.free_cam, st));
     HIPCHK(h->o_cam.upload(s.o_cam, st));
     HIPCHK(h->o_pt.upload(s.o_pt, st));
     HIPCHK(h->o_lcam.upload(s.o_lcam, st));

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void k_build_heavy(const BuildArgs A, const He
         const int cam = A.o_cam[ob + o];
         const double2 xy = reinterpret_cast<const double2 *>(A.o_xy)[ob + o];
         CamAux ca;
-        load_aux(A.aux, cam, ca);
+        load_aux_local(A.aux, cam, ca);  // (local rotation tangent: see load_aux_local)
         ObsLin Ln;
         linearize(ca, X0, X1, X2, xy.x, xy.y, A.loss, A.inv_fs2, floor_now, Ln);
         cost += A.half_fs2 * Ln.rho_sum;
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void k_build_heavy(const BuildArgs A, const He
         }
         const double2 xy = reinterpret_cast<const double2 *>(A.o_xy)[ob + o];
         CamAux ca;
-        load_aux(A.aux, cam, ca);
+        load_aux_local(A.aux, cam, ca);  // (local rotation tangent: see load_aux_local)
         ObsLin Ln;
         linearize(ca, X0, X1, X2, xy.x, xy.y, A.loss, A.inv_fs2, floor_now, Ln);
 #pragma unroll

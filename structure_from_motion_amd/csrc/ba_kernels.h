@@ -89,13 +89,24 @@ __device__ __forceinline__ double block_max256(double v, double *scratch) {
     do {                                                                          \
         if (STAMP && tid == 0) A.stamps[(size_t)ck * 12 + (i)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
+// LDS row of an observation in k_build: T' (3x3, row-major) and Y = R X; one pad double makes the row stride 26 banks,
+// so 32 lanes reading the same column of 32 different rows hit 32 different bank pairs (stride 24 would repeat after 8)
+#ifndef BA_T_STRIDE
+#define BA_T_STRIDE 13
+#endif
+constexpr int T_STRIDE = BA_T_STRIDE;
 constexpr int U_REPLICAS = 4;
 constexpr int U_REP_STRIDE = CHUNK_CAMS * 27 + 20;  // doubles; 776 = 16 banks (of 4 bytes) past a multiple of 64
 constexpr int P_REP_BASE = U_REPLICAS * U_REP_STRIDE + 6;  // second replica of the per-point sums, behind the camera replicas
 static_assert(P_REP_BASE + CHUNK_PTS * 9 <= CHUNK_OBS * 18, "the replicas live in the T buffer");
-template <bool STAMP>
+// LOSS: the robust loss as a compile-time constant (huber, the only kind the reference uses), or -1 for A.loss (the
+// generic switch carries the polynomial constants of log1p / atan through the kernel's registers).
+template <bool STAMP, int LOSS>
 __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_build(const BuildArgs A) {
-    __shared__ __attribute__((aligned(16))) double sT[CHUNK_OBS * 18];   // T = W L^-T per observation (6x3)
+    // phase 1: replicas of the camera / point sums; then per observation T' (3x3) and Y = R X at stride T_STRIDE -- the
+    // 6x3 block T = W L^-T of the observation is [[Y]x T'; T'] in the local rotation tangent (load_aux_local), so 12
+    // doubles stand for 18; after phase 3 the parked partial Schur blocks (36 doubles per lane pair)
+    __shared__ __attribute__((aligned(16))) double sT[CHUNK_OBS * 18];
     __shared__ __attribute__((aligned(16))) double sP[CHUNK_PTS * 9];    // per point: V(6) g_p(3), then L^-1(6) u(3)
     __shared__ __attribute__((aligned(16))) double sC[CHUNK_CAMS * 33];  // per local camera: U(21) g_c(6) g_red part(6)
     __shared__ double sRed[8];
@@ -139,7 +150,7 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
     const int lc_ld = A.o_lcam[oo];
     const double2 xy = reinterpret_cast<const double2 *>(A.o_xy)[oo];
     CamAux ca;
-    load_aux(A.aux, cam, ca);
+    load_aux_local(A.aux, cam, ca);
     const double X0 = A.points[3 * (size_t)p], X1 = A.points[3 * (size_t)p + 1], X2 = A.points[3 * (size_t)p + 2];
     const double floor_now = A.state->floor;
     for (int i = tid; i < npts * 9; i += CHUNK_OBS) sP[i] = 0.0;
@@ -153,11 +164,12 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
     if (tid < ncam) sCam[tid] = st_cam;
     if (has_pg) sPg[tid] = st_pg;
     if (has_slot) sSlot[tid] = st_slot;
-    __syncthreads();
+    lds_barrier();
 
     BA_STAMP(1);
     // ---- phase 1: one observation per lane ------------------------------------------------
-    double W[18];
+    double Wt[9];   // rows 3..5 of W = Jc'^T wh Jp (the translation rows: P^T wh Jp)
+    double Yr[3];   // R X
     double vs[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) vs[k] = 0.0;
@@ -169,8 +181,9 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
         lc = lc_ld;
         sLc[tid] = (unsigned char)lc;
         ObsLin L;
-        linearize(ca, X0, X1, X2, xy.x, xy.y, A.loss, A.inv_fs2, floor_now, L);
+        linearize(ca, X0, X1, X2, xy.x, xy.y, LOSS >= 0 ? LOSS : A.loss, A.inv_fs2, floor_now, L);
         cost_loc = A.half_fs2 * L.rho_sum;
+        Yr[0] = L.Y[0]; Yr[1] = L.Y[1]; Yr[2] = L.Y[2];
         double wJp[2][3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) { wJp[0][j] = L.wh[0] * L.Jp[0][j]; wJp[1][j] = L.wh[1] * L.Jp[1][j]; }
@@ -189,9 +202,9 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
 #pragma unroll
             for (int i = 0; i < 6; ++i) { wJc[0][i] = L.wh[0] * L.Jc[0][i]; wJc[1][i] = L.wh[1] * L.Jc[1][i]; }
 #pragma unroll
-            for (int i = 0; i < 6; ++i)
+            for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int j = 0; j < 3; ++j) W[i * 3 + j] = wJc[0][i] * L.Jp[0][j] + wJc[1][i] * L.Jp[1][j];
+                for (int j = 0; j < 3; ++j) Wt[i * 3 + j] = wJc[0][3 + i] * L.Jp[0][j] + wJc[1][3 + i] * L.Jp[1][j];
             if (lc >= 0) {
                 // per-camera U (21) and g_c (6): LDS atomics into the camera's tile.  (A gather through a camera-sorted
                 // observation list, without atomics, won at two workgroups per CU; at three the VALU is the scarcer
@@ -226,7 +239,7 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
 #pragma unroll
         for (int k = 0; k < 9; ++k) atomicAdd(&vp[k], vs[k]);
     }
-    __syncthreads();
+    lds_barrier();
 
     BA_STAMP(3);
     // camera tiles = sum of their replicas (highest lanes first: the low lanes have a point each in phase 2a)
@@ -280,51 +293,55 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
         const double cs = wave_sum_dpp(cost_loc), gm = wave_max_dpp(gmax_loc);
         if ((tid & 63) == 0) { sRed[tid >> 6] = cs; sRed[4 + (tid >> 6)] = gm; }
     }
-    __syncthreads();
+    lds_barrier();
     if (tid == 0) {
         A.ck_cost[ck] = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
         A.ck_gmax[ck] = fmax(fmax(sRed[4], sRed[5]), fmax(sRed[6], sRed[7]));
     }
 
     BA_STAMP(6);
-    // ---- phase 2b: T = W L^-T into LDS (overwrites the phase-1 staging) ---------------------------
+    // ---- phase 2b: T' = Wt L^-T and Y into LDS (overwrites the phase-1 staging) ---------------------------
     if (act && lc != -2) {
         const double *vp = &sP[lp * 9];
         const double i00 = vp[0], i10 = vp[1], i11 = vp[2], i20 = vp[3], i21 = vp[4], i22 = vp[5];
-        const double u0 = vp[6], u1 = vp[7], u2 = vp[8];
-        double *tp = &sT[tid * 18];
-        double t[18];
+        double *tp = &sT[tid * T_STRIDE];
+        double t[9];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            t[i * 3] = W[i * 3] * i00;
-            t[i * 3 + 1] = W[i * 3] * i10 + W[i * 3 + 1] * i11;
-            t[i * 3 + 2] = W[i * 3] * i20 + W[i * 3 + 1] * i21 + W[i * 3 + 2] * i22;
+        for (int i = 0; i < 3; ++i) {
+            t[i * 3] = Wt[i * 3] * i00;
+            t[i * 3 + 1] = Wt[i * 3] * i10 + Wt[i * 3 + 1] * i11;
+            t[i * 3 + 2] = Wt[i * 3] * i20 + Wt[i * 3 + 1] * i21 + Wt[i * 3 + 2] * i22;
         }
 #pragma unroll
-        for (int k = 0; k < 18; ++k) tp[k] = t[k];
-        if (lc == -1) {
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-                atomicAdd(&A.gred[(size_t)fcam * 6 + i], -(t[i * 3] * u0 + t[i * 3 + 1] * u1 + t[i * 3 + 2] * u2));
+        for (int k = 0; k < 9; ++k) tp[k] = t[k];
+        tp[9] = Yr[0]; tp[10] = Yr[1]; tp[11] = Yr[2];
+        if (lc == -1) {  // camera without a tile: its part of the reduced gradient, -T u = -[Y x w; w], w = T' u
+            const double u0 = vp[6], u1 = vp[7], u2 = vp[8];
+            const double w0 = t[0] * u0 + t[1] * u1 + t[2] * u2, w1 = t[3] * u0 + t[4] * u1 + t[5] * u2,
+                         w2 = t[6] * u0 + t[7] * u1 + t[8] * u2;
+            double *d = &A.gred[(size_t)fcam * 6];
+            atomicAdd(&d[0], -(Yr[1] * w2 - Yr[2] * w1));
+            atomicAdd(&d[1], -(Yr[2] * w0 - Yr[0] * w2));
+            atomicAdd(&d[2], -(Yr[0] * w1 - Yr[1] * w0));
+            atomicAdd(&d[3], -w0); atomicAdd(&d[4], -w1); atomicAdd(&d[5], -w2);
         }
     }
-    __syncthreads();
+    lds_barrier();
     BA_STAMP(7);
     BA_STAMP(8);
 
     // ---- phase 3: Schur-complement blocks and reduced gradient ----------------------------------
     // The chunk's (observation i, observation j) entries come in groups of PAIR_RUN entries of ONE camera pair
-    // (ba_symbolic.cpp).  Lane pair g reduces group g: each lane takes FOUR of the eight entries and forms their whole
-    // 6x6 products -sum T_i T_j^T in registers, so every T row of an entry is read from LDS exactly once (39 doubles per
-    // entry; splitting the block by rows instead read T_j twice: 60).  The odd lane numbers its rows from 3, so that
-    // accumulators 0..17 of both lanes are the rows they keep: one DPP exchange of the other 18 sums the two lanes.
-    // No LDS atomics: once every lane is done with T, the partial blocks are parked in sT (exactly 36 doubles per lane
-    // pair) and phase 4 sums the groups of each pair.  Self entries (i == j) also carry -T_i u_p of the reduced
-    // gradient (camera tile, LDS atomics: few).  Groups beyond the first CHUNK_OBS / 2 of a chunk (rare: long tracks)
-    // are done first and go to HBM straight from the registers.
+    // (ba_symbolic.cpp).  Lane pair g reduces group g: each lane forms the whole 6x6 products sum T_i T_j^T of FOUR
+    // entries in registers.  With T = [[Y]x T'; T'] the bottom rows of T_i T_j^T are B = [N [Yj]x^T | N], N = T'_i T'_j^T
+    // (row r of N [Yj]x^T is Yj x n_r), and the top rows are [Yi]x B, streamed row by row so that only one row of B is
+    // live: 27 doubles read from LDS and 99 FMA-class instructions per entry, where the full 6x3 rows took 39 and 117.
+    // Then the two lanes are summed by DPP and each parks one half of the block in sT once every lane is done with T
+    // (exactly 36 doubles per lane pair); phase 4 sums the groups of each pair.  No LDS atomics.  Self entries (i == j)
+    // also carry -T_i u_p of the reduced gradient (camera tile, LDS atomics: few).  Groups beyond the first
+    // CHUNK_OBS / 2 of a chunk (rare: long tracks) are done first and go to HBM straight from the registers.
     {
-        double acc[36];
-        const int rot = half * 9;  // the odd lane reads rows 3..5 of T_i first
+        double acc[36];  // + sum T_i T_j^T (the sign is applied when the block leaves the registers)
         for (int round = (rounds > 0 ? rounds : 1) - 1; round >= 0; --round) {
             unsigned en[PAIR_RUN / 2];
             if (round > 0) {
@@ -345,61 +362,75 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
                 const unsigned ent = en[e];
                 const unsigned ec = ent == PAIR_NULL ? 0u : ent;  // a null entry reads observation 0: harmless
                 const int oi = ec & 255u, oj = (ec >> 8) & 255u;
-                const double *ti = &sT[oi * 18], *tj = &sT[oj * 18], *uu = &sP[(int)sLp[oi] * 9 + 6];
-                double tb[18], tu[3];
+                const double *ti = &sT[oi * T_STRIDE], *tj = &sT[oj * T_STRIDE], *uu = &sP[(int)sLp[oi] * 9 + 6];
                 const bool real = ent != PAIR_NULL, self = real && oi == oj;
                 if (self) self_lc = sLc[oi];
+                double Tj[9], Yj[3], Yi[3], tu[3];
 #pragma unroll
-                for (int k = 0; k < 18; ++k) tb[k] = tj[k];
+                for (int k = 0; k < 9; ++k) Tj[k] = tj[k];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) tu[k] = uu[k];
+                for (int k = 0; k < 3; ++k) { Yj[k] = tj[9 + k]; Yi[k] = ti[9 + k]; tu[k] = uu[k]; }
 #pragma unroll
-                for (int hh = 0; hh < 3; ++hh) {  // two row slots at a time: six doubles of T_i live, not eighteen
-                    double ta[6];
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const int s3 = (hh * 2 + q) * 3;                                  // slot s holds row (s + 3 half) mod 6
-                        const double *tis = ti + (s3 + rot >= 18 ? s3 + rot - 18 : s3 + rot);
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) ta[q * 3 + k] = tis[k];
-                    }
+                for (int r = 0; r < 3; ++r) {
+                    const double a0 = ti[3 * r], a1 = ti[3 * r + 1], a2 = ti[3 * r + 2];
                     if (real) {
+                        double B[6];
+                        B[3] = a0 * Tj[0] + a1 * Tj[1] + a2 * Tj[2];
+                        B[4] = a0 * Tj[3] + a1 * Tj[4] + a2 * Tj[5];
+                        B[5] = a0 * Tj[6] + a1 * Tj[7] + a2 * Tj[8];
+                        B[0] = Yj[1] * B[5] - Yj[2] * B[4];
+                        B[1] = Yj[2] * B[3] - Yj[0] * B[5];
+                        B[2] = Yj[0] * B[4] - Yj[1] * B[3];
+                        const int s1 = (r + 1) % 3, s2 = (r + 2) % 3;   // (Yi x b)_{r+1} gets +Yi_{r+2} b_r, (Yi x b)_{r+2} gets -Yi_{r+1} b_r
 #pragma unroll
-                        for (int rr = 0; rr < 2; ++rr) {
-#pragma unroll
-                            for (int c = 0; c < 6; ++c)
-                                acc[(hh * 2 + rr) * 6 + c] -= ta[rr * 3] * tb[c * 3] + ta[rr * 3 + 1] * tb[c * 3 + 1] + ta[rr * 3 + 2] * tb[c * 3 + 2];
-                            if (self) gacc[hh * 2 + rr] -= ta[rr * 3] * tu[0] + ta[rr * 3 + 1] * tu[1] + ta[rr * 3 + 2] * tu[2];
+                        for (int c = 0; c < 6; ++c) {
+                            acc[(3 + r) * 6 + c] += B[c];
+                            acc[s1 * 6 + c] += Yi[s2] * B[c];
+                            acc[s2 * 6 + c] -= Yi[s1] * B[c];
+                        }
+                        if (self) {
+                            const double w = a0 * tu[0] + a1 * tu[1] + a2 * tu[2];
+                            gacc[3 + r] += w;
+                            gacc[s1] += Yi[s2] * w;
+                            gacc[s2] -= Yi[s1] * w;
                         }
                     }
                 }
             }
-            if (self_lc >= 0 && self_lc < CHUNK_CAMS) {
+            if (self_lc >= 0 && self_lc < CHUNK_CAMS) {   // (both lanes add their own four entries)
                 double *d = &sC[self_lc * 33 + 27];
 #pragma unroll
-                for (int rr = 0; rr < 3; ++rr) {  // slots 0..2 are rows 3 half .., slots 3..5 the other three
-                    atomicAdd(&d[half * 3 + rr], gacc[rr]);
-                    atomicAdd(&d[3 - half * 3 + rr], gacc[3 + rr]);
-                }
+                for (int k = 0; k < 6; ++k) atomicAdd(&d[k], -gacc[k]);
             }
-            if (round > 0 && en[0] != PAIR_NULL) {
-                double *d = &A.S[(size_t)A.ck_pair_slot[qb + (int)(en[0] >> 16)] * 36];
+            // sum of the two lanes; each lane keeps one half of the block
 #pragma unroll
-                for (int k = 0; k < 18; ++k) {
-                    atomicAdd(&d[half * 18 + k], acc[k]);
-                    atomicAdd(&d[18 - half * 18 + k], acc[18 + k]);
+            for (int k = 0; k < 36; ++k) acc[k] += dpp_f64<0xB1>(acc[k]);
+            if (round > 0) {
+                // (the group's first entry sits in the EVEN lane; the odd lane has none when the group holds at most four)
+                const unsigned first = (unsigned)__builtin_amdgcn_update_dpp(0, (int)en[0], 0xA0, 0xf, 0xf, true);  // quad_perm [0,0,2,2]
+                if (first != PAIR_NULL) {
+                    double *d = &A.S[(size_t)A.ck_pair_slot[qb + (int)(first >> 16)] * 36];
+                    if (half == 0) {
+#pragma unroll
+                        for (int k = 0; k < 18; ++k) atomicAdd(&d[k], -acc[k]);
+                    } else {
+#pragma unroll
+                        for (int k = 18; k < 36; ++k) atomicAdd(&d[k], -acc[k]);
+                    }
                 }
             }
         }
-        // round 0 is still in the registers: add the partner lane's sums of the rows this lane keeps
+        lds_barrier();  // every lane is done reading T
+        double *park = &sT[(tid >> 1) * 36];
+        if (half == 0) {
 #pragma unroll
-        for (int k = 0; k < 18; ++k) acc[k] += dpp_f64<0xB1>(acc[18 + k]);
-        __syncthreads();  // every lane is done reading T
-        double *park = &sT[(tid >> 1) * 36 + half * 18];
+            for (int k = 0; k < 18; ++k) park[k] = -acc[k];
+        } else {
 #pragma unroll
-        for (int k = 0; k < 18; ++k) park[k] = acc[k];
+            for (int k = 18; k < 36; ++k) park[k] = -acc[k];
+        }
     }
-    __syncthreads();
+    lds_barrier();
 
     BA_STAMP(9);
     // ---- phase 4: one flush per chunk (fp64 atomics to HBM) ------------------------------------------
@@ -480,6 +511,76 @@ __device__ __forceinline__ bool spd6_inverse(const double *__restrict__ Ain, dou
             out[j * 6 + i] = s;
         }
     return true;
+}
+
+// The build kernels linearise in the local rotation tangent (load_aux_local).  This brings the accumulated reduced
+// system to the rvec parameters the solver steps in, once per build pass: with D = diag(Jl, I) per camera,
+// U = D^T U' D, g = D^T g', S_ij = D_i^T S'_ij D_j.  One thread per upper block, then one per free camera.
+__global__ void k_apply_jl(int nf, int n_upper, const long long *__restrict__ keys, const int *__restrict__ free_cam,
+                           const double *__restrict__ aux, double *__restrict__ S, double *__restrict__ U,
+                           double *__restrict__ gc, double *__restrict__ gred) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_upper) {
+        const int i = (int)(keys[t] >> 32), j = (int)(keys[t] & 0xffffffff);
+        const double *Ji = aux + (size_t)free_cam[i] * BA_CAM_AUX + 9, *Jj = aux + (size_t)free_cam[j] * BA_CAM_AUX + 9;
+        double *blk = &S[(size_t)t * 36];
+        double B[36], ji[9], jj[9];
+#pragma unroll
+        for (int k = 0; k < 36; ++k) B[k] = blk[k];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { ji[k] = Ji[k]; jj[k] = Jj[k]; }
+        double T3[18];  // Ji^T * (top three rows)
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) T3[r * 6 + c] = ji[r] * B[c] + ji[3 + r] * B[6 + c] + ji[6 + r] * B[12 + c];
+#pragma unroll
+        for (int k = 0; k < 18; ++k) B[k] = T3[k];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {  // (left three columns) * Jj
+            const double b0 = B[r * 6], b1 = B[r * 6 + 1], b2 = B[r * 6 + 2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) B[r * 6 + c] = b0 * jj[c] + b1 * jj[3 + c] + b2 * jj[6 + c];
+        }
+#pragma unroll
+        for (int k = 0; k < 36; ++k) blk[k] = B[k];
+    } else if (t < n_upper + nf) {
+        const int f = t - n_upper;
+        const double *J = aux + (size_t)free_cam[f] * BA_CAM_AUX + 9;
+        double jl[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) jl[k] = J[k];
+        double *u = &U[(size_t)f * 21];
+        double B[36];
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = r; c < 6; ++c) B[r * 6 + c] = B[c * 6 + r] = u[ut6(r, c)];
+        double T3[18];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) T3[r * 6 + c] = jl[r] * B[c] + jl[3 + r] * B[6 + c] + jl[6 + r] * B[12 + c];
+#pragma unroll
+        for (int k = 0; k < 18; ++k) B[k] = T3[k];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const double b0 = B[r * 6], b1 = B[r * 6 + 1], b2 = B[r * 6 + 2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) B[r * 6 + c] = b0 * jl[c] + b1 * jl[3 + c] + b2 * jl[6 + c];
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = r; c < 6; ++c) u[ut6(r, c)] = (r < 3 && c < 3 && r != c) ? 0.5 * (B[r * 6 + c] + B[c * 6 + r]) : B[r * 6 + c];
+        double *g1 = &gc[(size_t)f * 6], *g2 = &gred[(size_t)f * 6];
+        const double a0 = g1[0], a1 = g1[1], a2 = g1[2], b0 = g2[0], b1 = g2[1], b2 = g2[2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            g1[r] = jl[r] * a0 + jl[3 + r] * a1 + jl[6 + r] * a2;
+            g2[r] = jl[r] * b0 + jl[3 + r] * b1 + jl[6 + r] * b2;
+        }
+    }
 }
 
 __global__ void k_finalize(int nf, const double *__restrict__ U, const double *__restrict__ gc, double *__restrict__ gred,
