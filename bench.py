@@ -8,9 +8,14 @@ camera system, reduced gradient) over the whole synthetic problem, inputs alread
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-N > 1: weak scaling -- every rank owns a Venice-sized point shard (993 923 points, ~5.0 M
-observations) of ONE problem with the 1778 cameras replicated; per step the ranks all-reduce the
-reduced camera system over RCCL.  value = observations of all ranks / max-over-ranks time.
+N > 1 (default --scaling strong, what BASELINE.json asks for): ONE problem, point-sharded over the N ranks
+(cameras replicated); per step every rank builds its partial reduced camera system and the ranks all-reduce it over
+RCCL (the library's own RCCL binding, no Python between kernels and collectives).  value = observations of the WHOLE
+problem / max-over-ranks time.
+  --workload venice1778   the Venice-shaped problem, cut N ways by dist.shard_points (same problem at every N)
+  --workload city10k      10 000 cameras, 20 M points, 100 M observations in total, generated per shard (rank r makes
+                          its 1/N of the points with its own seed; cameras from one seed)
+--scaling weak: every rank owns a full-size shard of its own (N times the work).
 """
 import argparse
 import json
@@ -66,9 +71,12 @@ def cpu_baseline(prob, budget_obs):
 
 
 def other_configs(_capi, synthetic):
-    """BASELINE.json's other single-GPU configurations, reported beside the headline line (not bench lines of their
-    own): the Temple-ring-shaped final BA as one host-to-host ba_solve call, and the Ladybug-1723 shape resident."""
+    """BASELINE.json's other single-GPU configurations and the non-banded solver case, reported beside the headline
+    line (not bench lines of their own)."""
     out = {}
+    # Temple-ring-shaped final BA, three ways: (1) one ba_solve call from ready arrays; (2) final_ba of the drop-in
+    # module from the reference's containers (image_data tuples, point lists) = what Reconstruction.py:302-304 pays,
+    # marshalling included; (3) the same through BASession (array marshalling, cached keypoints)
     p = synthetic.make_config("temple")
     arr = _capi.Arrays.from_dict(p)
     t0 = time.perf_counter()
@@ -76,7 +84,23 @@ def other_configs(_capi, synthetic):
     out["temple_final_ba"] = {"cameras": len(p["cam_pose"]), "points": len(p["points"]), "observations": len(p["obs_cam"]),
                               "status": s["status"], "lm_steps": s["iterations"], "cost": [s["initial_cost"], s["final_cost"]],
                               "solve_ms": s["t_solve_ms"], "setup_ms": s["t_setup_ms"],
-                              "wall_ms_host_to_host": (time.perf_counter() - t0) * 1e3}
+                              "wall_ms_from_arrays": (time.perf_counter() - t0) * 1e3}
+    try:
+        import contextlib
+        import io
+        from structure_from_motion_amd import BundleAdjustment as BA
+        from structure_from_motion_amd.session import BASession
+        ids, image_data, pts = synthetic.to_image_data(p)
+        for name, fn in (("wall_ms_final_ba_dict_api", lambda d: BA.final_ba(d, pts, ids, verbose=False)),
+                         ("wall_ms_final_ba_session", lambda d: BASession().final_ba(d, pts, ids, verbose=False))):
+            d = dict(image_data)
+            t0 = time.perf_counter()
+            with contextlib.redirect_stdout(io.StringIO()):
+                _pts, _d, ok = fn(d)
+            out["temple_final_ba"][name] = (time.perf_counter() - t0) * 1e3
+            out["temple_final_ba"][name.replace("wall_ms", "ok")] = bool(ok)
+    except Exception as e:  # never lose the headline line over a side measurement
+        out["temple_final_ba"]["host_api_error"] = repr(e)
     p = synthetic.make_config("ladybug1723")
     with _capi.Handle(_capi.Arrays.from_dict(p), loss="huber", f_scale=1.0, max_iter=300) as h:
         h.build_bench(1e-4, warmup=0, reps=3)
@@ -88,6 +112,21 @@ def other_configs(_capi, synthetic):
     out["ladybug1723"] = {"observations": len(p["obs_cam"]), "build_ms": ms_pass, "k_build_ms": ms_k,
                           "observations_per_sec": len(p["obs_cam"]) / (ms_pass * 1e-3),
                           "lm_iters_per_sec": max(s["iterations"], 1) / dt, "lm_pcg_iterations": s["pcg_iterations"]}
+    # NOT banded: 1778 cameras on a closed ring (loop closure), long tracks -> block-Jacobi PCG on the block-sparse S
+    p = synthetic.make_config("ring1778_loop")
+    with _capi.Handle(_capi.Arrays.from_dict(p), loss="huber", f_scale=1.0, max_iter=300) as h:
+        h.build_bench(1e-4, warmup=0, reps=3)
+        ms_pass, ms_k = h.build_bench(1e-4, warmup=0, reps=10)
+        t0 = time.perf_counter()
+        s = h.run(10)
+        h.synchronize()
+        dt = time.perf_counter() - t0
+    out["ring1778_loop"] = {"cameras": len(p["cam_pose"]), "observations": len(p["obs_cam"]), "solver": "block-Jacobi PCG (pattern is not banded)",
+                            "build_ms": ms_pass, "observations_per_sec": len(p["obs_cam"]) / (ms_pass * 1e-3),
+                            "lm_steps": s["iterations"], "lm_iters_per_sec": max(s["iterations"], 1) / dt,
+                            "lm_pcg_iterations": s["pcg_iterations"],
+                            "pcg_iterations_per_lm_step": s["pcg_iterations"] / max(s["iterations"], 1),
+                            "cost": [s["initial_cost"], s["final_cost"]]}
     return out
 
 
@@ -96,7 +135,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="venice1778")
+    ap.add_argument("--workload", default="venice1778", choices=["venice1778", "ladybug1723", "city10k"])
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong = ONE problem cut N ways (default, BASELINE.json); weak = a full-size shard per rank")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink points/observations (debug only)")
     ap.add_argument("--lm-steps", type=int, default=10)
     ap.add_argument("--cpu-sample-obs", type=int, default=150000)
@@ -131,9 +172,28 @@ def main():
 
     nc, n_pts, n_obs = synthetic.SHAPES[args.workload]
     n_pts, n_obs = max(int(n_pts * args.scale), 64), max(int(n_obs * args.scale), 256)
-    # one problem; rank r owns point shard r (own seed), cameras identical on every rank (cam_seed)
     idx = {"ladybug1723": 3, "venice1778": 4, "city10k": 5}[args.workload]
-    prob = synthetic.make_street(nc, n_pts, n_obs, seed=1233 + idx + 1000 * rank, cam_seed=1233 + idx)
+    strong = args.scaling == "strong"
+    if not strong:
+        # weak: rank r owns a full-size point shard of its own (own seed); cameras identical on every rank (cam_seed)
+        prob = synthetic.make_street(nc, n_pts, n_obs, seed=1233 + idx + 1000 * rank, cam_seed=1233 + idx)
+        total_obs, total_pts = n_obs * world, n_pts * world
+        how = "every rank a full-size shard of its own"
+    elif args.workload == "city10k":
+        # ONE problem of n_pts points / n_obs observations in total, generated per shard (no rank ever
+        # builds the whole 100 M-observation problem): rank r makes its 1/N of the points, cameras from one seed
+        sp, so = n_pts // world, n_obs // world
+        prob = synthetic.make_street(nc, sp, so, seed=1233 + idx + 1000 * rank, cam_seed=1233 + idx)
+        total_obs, total_pts = so * world, sp * world
+        how = "one problem generated per shard"
+    else:
+        # ONE problem, the same at every N (same seed on every rank), cut into N point shards balanced by observations
+        full = synthetic.make_street(nc, n_pts, n_obs, seed=1233 + idx)
+        prob = badist.shard_points(full, rank, world)[0] if world > 1 else full
+        del full
+        total_obs, total_pts = n_obs, n_pts
+        how = "one problem cut by dist.shard_points"
+    my_obs, my_pts = len(prob["obs_cam"]), len(prob["points"])
     arr = _capi.Arrays.from_dict(prob)
     lam = 1e-4
     opts = dict(loss="huber", f_scale=1.0, max_iter=300, device=local_rank)
@@ -159,12 +219,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt * 1e3 / args.steps
-    total_obs = n_obs * world
     value = total_obs / (dt / args.steps)
 
     # dominant kernel: HIP events around its launch on the library's stream (per-rank shard)
     _, ms_kernel = h.build_bench(lam, warmup=0, reps=min(args.steps, 10))
-    alg = algorithmic_bytes(n_obs, n_pts, nc)
+    alg = algorithmic_bytes(my_obs, my_pts, nc)   # of this rank's launch
     achieved = alg / (ms_kernel * 1e-3) / 1e9
     traffic = None
     tf = os.path.join(ROOT, "profiles", "traffic.json")
@@ -176,8 +235,8 @@ def main():
     # the kernel sits near the ridge: the fp64 VALU ceiling next to the HBM one.  Algorithmic flops:
     # 430 per observation (projection, analytic blocks, U/V/W/g) + 108 + 108 (L + 1) per observation for the explicit
     # Schur complement at mean track length L + 50 per point (3x3 factor)
-    track = n_obs / max(n_pts, 1)
-    flops = n_obs * (430.0 + 108.0 + 108.0 * (track + 1.0)) + 50.0 * n_pts
+    track = my_obs / max(my_pts, 1)
+    flops = my_obs * (430.0 + 108.0 + 108.0 * (track + 1.0)) + 50.0 * my_pts
     roofline["fp64_valu"] = {"achieved": flops / (ms_kernel * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": flops / (ms_kernel * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, "algorithmic_flops_per_launch": flops}
 
@@ -192,10 +251,12 @@ def main():
     out = {
         "metric": "observations/sec (residual+Jacobian+Schur build)", "value": value, "unit": "observations/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{args.workload} shape per GPU: {nc} cameras (replicated), {n_pts} points, "
-                               f"{n_obs} observations per rank; huber f_scale=1.0; lambda={lam:g}",
-                   "scale": args.scale, "cameras": nc, "points_per_gpu": n_pts, "observations_per_gpu": n_obs,
+        "higher_is_better": True, "scaling": args.scaling if world > 1 else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{args.workload} shape: {nc} cameras (replicated), {total_pts} points, {total_obs} observations in "
+                               f"total over {world} GPU(s) ({how}); huber f_scale=1.0; lambda={lam:g}",
+                   "scale": args.scale, "cameras": nc, "points_total": total_pts, "observations_total": total_obs,
+                   "points_rank0": my_pts, "observations_rank0": my_obs,
+                   "collectives": ("RCCL bound in libba_hip.so" if backend == "nccl" else backend) if world > 1 else None,
                    "parallelism": f"point-sharded x{world}" if world > 1 else "single GPU"},
         "lm_iters_per_sec": lm_rate, "lm_steps": summ["iterations"], "lm_pcg_iterations": summ["pcg_iterations"],
         "lm_cost": [summ["initial_cost"], summ["final_cost"]],

@@ -176,6 +176,14 @@ int ba_set_collective(BaHandle *h, BaCollectiveFn fn, void *user, int32_t rank, 
  * reference is single-process.) */
 int ba_set_collective_mode(BaHandle *h, int32_t stream_ordered);
 int ba_get_stream(BaHandle *h, void **stream); /* the hipStream_t every kernel of this handle runs on */
+/* Built-in collectives: RCCL bound inside the library (librccl.so is opened at run time), so that a sharded solve has
+ * no host code -- no Python callback -- between its kernels and its collectives: ncclAllReduce / ncclBroadcast are
+ * enqueued in place on the handle's stream.  Rank 0 calls ba_rccl_unique_id (128 bytes) and hands the id to the other
+ * ranks by whatever channel the launcher has (torch.distributed, MPI, a file); every rank then calls ba_rccl_init on its
+ * handle, collectively, after ba_set_pattern.  The communicator belongs to the handle.  A later ba_set_collective
+ * replaces it with the callback again.  (No reference counterpart: the reference is single-process.) */
+int ba_rccl_unique_id(void *out_id128);
+int ba_rccl_init(BaHandle *h, const void *id128, int32_t rank, int32_t world);
 /* One residual + Jacobian + Schur-complement pass at the current state with damping lambda:
  * (x, lambda) -> cost, reduced camera system S, reduced gradient.  The benchmark unit. */
 int ba_build(BaHandle *h, double lambda);

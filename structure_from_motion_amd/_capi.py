@@ -25,7 +25,7 @@ EXPORTED = [
     "ba_get_pattern", "ba_set_pattern", "ba_set_collective", "ba_build", "ba_build_bench", "ba_run",
     "ba_get_state", "ba_get_cost", "ba_get_reduced_system", "ba_get_reduced_blocks", "ba_synchronize",
     "ba_set_values", "ba_set_collective_mode", "ba_get_stream", "ba_eval_cost_noalloc",
-    "ba_eval_reprojection_errors_rt", "ba_get_reprojection_errors",
+    "ba_eval_reprojection_errors_rt", "ba_get_reprojection_errors", "ba_rccl_unique_id", "ba_rccl_init",
 ]
 
 
@@ -99,6 +99,8 @@ def load():
     lib.ba_eval_reprojection_errors.argtypes = [P(BaProblem), C.c_void_p, C.c_void_p]
     lib.ba_eval_reprojection_errors_rt.argtypes = [P(BaProblem), C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ba_get_reprojection_errors.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ba_rccl_unique_id.argtypes = [C.c_void_p]
+    lib.ba_rccl_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
     lib.ba_analyze.argtypes = [P(BaProblem), P(BaAnalysis)]
     lib.ba_create.argtypes = [P(BaProblem), P(BaOptions)]
     lib.ba_create.restype = C.c_void_p
@@ -233,6 +235,13 @@ def solve(arr, **opts):
     return s.as_dict()
 
 
+def rccl_unique_id():
+    """128-byte id for ``Handle.rccl_init`` (rank 0 makes it, every rank uses the same one)."""
+    buf = C.create_string_buffer(128)
+    check(load().ba_rccl_unique_id(buf))
+    return buf.raw
+
+
 class Handle:
     """Device-resident problem (``ba_create`` ... ``ba_destroy``)."""
 
@@ -343,6 +352,13 @@ class Handle:
                 return 1
         self._cb = COLLECTIVE_FN(tramp)
         check(self._lib.ba_set_collective(self.h, self._cb, None, int(rank), int(world)))
+
+    def rccl_init(self, unique_id, rank, world):
+        """Built-in RCCL collectives on this handle's stream (``ba_rccl_init``); ``unique_id``: the 128 bytes of
+        :func:`rccl_unique_id`, the same on every rank.  Collective over the ranks."""
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        check(self._lib.ba_rccl_init(self.h, buf, int(rank), int(world)))
+        self._cb = None
 
     def reduced_system(self, want_points=True, want_dense=True):
         nf = int((self.arr.cam_fixed == 0).sum())

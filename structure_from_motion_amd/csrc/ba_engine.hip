@@ -5,6 +5,7 @@
 // All kernels run on the handle's own HIP stream; the host only reads back one small LmState
 // per LM step (accept flag / termination) -- the damping and accept logic itself runs on device.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <chrono>
 #include <cmath>
@@ -140,6 +141,42 @@ int fetch_problem(const BaProblem *p, HostProblem &h, bool indices_only) {
     return BA_OK;
 }
 
+// ---- RCCL, bound at run time (no link-time dependency: the library also loads on machines without it) -------------
+// Only the five entry points the sharded solve needs; types as in rccl.h (ncclUniqueId = 128 opaque bytes,
+// ncclDouble = 8, ncclSum = 0, ncclMax = 2).
+struct RcclUniqueId { char internal[128]; };
+struct RcclApi {
+    int (*GetUniqueId)(RcclUniqueId *) = nullptr;
+    int (*CommInitRank)(void **, int, RcclUniqueId, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+RcclApi *rccl_api() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // the copy that is already in the process (torch ships its own librccl.so) first: two RCCL instances in one
+        // process would each bring up their own transports
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        void *lib = nullptr;
+        for (const char *n : names)
+            if ((lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+        for (size_t i = 0; !lib && i < sizeof names / sizeof names[0]; ++i) lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) return;
+        api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+        api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+        api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+        api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(lib, "ncclAllReduce"));
+        api.Broadcast = reinterpret_cast<decltype(api.Broadcast)>(dlsym(lib, "ncclBroadcast"));
+        api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+        api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce && api.Broadcast;
+    });
+    return api.ok ? &api : nullptr;
+}
+
 }  // namespace
 
 using namespace ba;
@@ -194,6 +231,7 @@ struct BaHandle {
     void *coll_user = nullptr;
     int rank = 0, world = 1;
     bool coll_stream_ordered = false;  // the callback enqueues on `stream`; no host synchronisation around it
+    void *rccl_comm = nullptr;         // ncclComm_t of the built-in RCCL collectives (ba_rccl_init); owned by the handle
     // bookkeeping
     int total_pcg = 0;
     double initial_cost = NAN;
@@ -201,6 +239,9 @@ struct BaHandle {
     double t_setup_ms = 0.0;
 
     ~BaHandle() {
+        if (rccl_comm) {
+            if (RcclApi *api = rccl_api()) (void)api->CommDestroy(rccl_comm);
+        }
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (ev2) (void)hipEventDestroy(ev2);
@@ -240,6 +281,16 @@ int upload_pattern(BaHandle *h) {
 }
 
 int call_coll(BaHandle *h, void *ptr, int64_t n, int op) {
+    if (h->rccl_comm) {
+        // built-in collectives: enqueued on the handle's stream, in place, no host code in between (the LM loop's only
+        // host round trip stays the accept / reject read-back)
+        RcclApi *api = rccl_api();
+        const int rc = op == BA_BROADCAST0 ? api->Broadcast(ptr, ptr, (size_t)n, 8 /* ncclDouble */, 0, h->rccl_comm, h->stream)
+                                           : api->AllReduce(ptr, ptr, (size_t)n, 8, op == BA_REDUCE_MAX ? 2 /* ncclMax */ : 0 /* ncclSum */,
+                                                            h->rccl_comm, h->stream);
+        if (rc != 0) return fail(BA_ERR_COMM, "RCCL collective failed: %s", api->GetErrorString ? api->GetErrorString(rc) : "?");
+        return BA_OK;
+    }
     if (!h->coll) return BA_OK;
     if (!h->coll_stream_ordered) HIPCHK(hipStreamSynchronize(h->stream));
     if (h->opt.verbose >= 3) { fprintf(stderr, "[ba_hip r%d] collective op %d n %lld\n", h->rank, op, (long long)n); fflush(stderr); }
@@ -800,10 +851,53 @@ int ba_set_pattern(BaHandle *h, const int32_t *pairs, int64_t n_pairs) {
 int ba_set_collective(BaHandle *h, BaCollectiveFn fn, void *user, int32_t rank, int32_t world) {
     if (!h) return fail(BA_ERR_INVALID, "null handle");
     if (world > BA_MAX_WORLD || rank < 0 || (world >= 1 && rank >= world)) return fail(BA_ERR_INVALID, "rank %d of %d (at most %d ranks)", rank, world, BA_MAX_WORLD);
+    if (h->rccl_comm) {   // a callback replaces the built-in RCCL collectives
+        if (RcclApi *api = rccl_api()) (void)api->CommDestroy(h->rccl_comm);
+        h->rccl_comm = nullptr;
+    }
     h->coll = fn;
     h->coll_user = user;
     h->rank = rank;
     h->world = world < 1 ? 1 : world;
+    return BA_OK;
+}
+
+int ba_rccl_unique_id(void *out_id128) {
+    if (!out_id128) return fail(BA_ERR_INVALID, "null argument");
+    RcclApi *api = rccl_api();
+    if (!api) return fail(BA_ERR_UNSUPPORTED, "librccl.so could not be loaded");
+    RcclUniqueId id;
+    const int rc = api->GetUniqueId(&id);
+    if (rc != 0) return fail(BA_ERR_COMM, "ncclGetUniqueId failed: %s", api->GetErrorString ? api->GetErrorString(rc) : "?");
+    memcpy(out_id128, &id, sizeof id);
+    return BA_OK;
+}
+
+namespace {
+int sentinel_collective(void *, int64_t, int32_t, void *) { return 1; }  // never called: call_coll takes the RCCL path first
+}
+
+int ba_rccl_init(BaHandle *h, const void *id128, int32_t rank, int32_t world) {
+    if (!h || !id128) return fail(BA_ERR_INVALID, "null argument");
+    if (world < 1 || world > BA_MAX_WORLD || rank < 0 || rank >= world) return fail(BA_ERR_INVALID, "rank %d of %d (at most %d ranks)", rank, world, BA_MAX_WORLD);
+    RcclApi *api = rccl_api();
+    if (!api) return fail(BA_ERR_UNSUPPORTED, "librccl.so could not be loaded");
+    (void)hipSetDevice(h->device);
+    if (h->rccl_comm) {
+        (void)api->CommDestroy(h->rccl_comm);
+        h->rccl_comm = nullptr;
+    }
+    RcclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    void *comm = nullptr;
+    const int rc = api->CommInitRank(&comm, world, id, rank);
+    if (rc != 0 || !comm) return fail(BA_ERR_COMM, "ncclCommInitRank failed: %s", api->GetErrorString ? api->GetErrorString(rc) : "?");
+    h->rccl_comm = comm;
+    h->coll = sentinel_collective;   // "this solve is sharded" for the code that only asks whether collectives are on
+    h->coll_user = nullptr;
+    h->coll_stream_ordered = true;
+    h->rank = rank;
+    h->world = world;
     return BA_OK;
 }
 

@@ -93,10 +93,15 @@ def shard_points(prob, rank, world):
     return shard, np.arange(lo, hi)
 
 
-def create_sharded_handle(shard, rank, world, group=None, stream_ordered=True, force_collectives=False, **opts):
-    """Handle for this rank's shard with the shared pattern and the RCCL collectives installed (stream-ordered on
-    the nccl backend unless ``stream_ordered=False``).  ``force_collectives`` installs them for a world of one as
-    well (tests: the whole sharded path on a single GPU)."""
+def create_sharded_handle(shard, rank, world, group=None, stream_ordered=True, force_collectives=False, native=None, **opts):
+    """Handle for this rank's shard with the shared pattern and the collectives installed.
+
+    ``native`` (default: on the nccl backend): the library's own RCCL binding (``ba_rccl_init``) -- ncclAllReduce /
+    ncclBroadcast enqueued on the handle's stream from C, no Python between the kernels and the collectives of an LM
+    step; torch.distributed only carries the pattern union and the 128-byte RCCL id, once.  Otherwise (gloo in the
+    tests, or ``native=False``) the collectives are torch.distributed calls behind the callback hook, stream-ordered on
+    the nccl backend unless ``stream_ordered=False``.  ``force_collectives`` installs them for a world of one as well
+    (tests: the whole sharded path on a single GPU)."""
     import torch.distributed as dist
     h = _capi.Handle(_capi.Arrays.from_dict(shard), **opts)
     if world > 1 or force_collectives:
@@ -105,6 +110,13 @@ def create_sharded_handle(shard, rank, world, group=None, stream_ordered=True, f
             dist.all_gather_object(out, obj, group=group)
             return out
         h.set_pattern(union_pattern(h.pattern(), gather))
-        coll = make_collective(group, h.stream() if stream_ordered else None)
-        h.set_collective(coll, rank, world, stream_ordered=coll.stream_ordered)
+        if native is None:
+            native = dist.get_backend(group) == "nccl"
+        if native:
+            box = [_capi.rccl_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, group=group)
+            h.rccl_init(box[0], rank, world)
+        else:
+            coll = make_collective(group, h.stream() if stream_ordered else None)
+            h.set_collective(coll, rank, world, stream_ordered=coll.stream_ordered)
     return h

@@ -112,7 +112,7 @@ def make_street(n_cams, n_points, n_obs, seed=0, noise=0.5, outlier_frac=0.01, m
 def make_ring(n_cams, n_points, seed=0, K=(1520.4, 1525.9, 302.32, 246.87), focal_jitter=0.02,
               noise=0.35, outlier_frac=0.0, visibility="dense", mean_track=4.0, n_fixed=1,
               n_seed_points=None, radius=4.0, sig_r=1e-3, sig_t=1e-2, sig_p=1e-2, n_unobserved=0,
-              max_track=24, n_landmarks=0):
+              max_track=24, n_landmarks=0, point_radius=None):
     """Temple / Fountain-shaped problem: cameras on a ring (or arc) of ``radius`` looking at a
     unit blob of points.
 
@@ -132,17 +132,26 @@ def make_ring(n_cams, n_points, seed=0, K=(1520.4, 1525.9, 302.32, 246.87), foca
         Rm = np.stack([xax, yax, zax], axis=0)  # world -> camera
         cam_pose_gt[i, :3] = matrix_to_rvec(Rm)
         cam_pose_gt[i, 3:] = -Rm @ C[i]
+    if point_radius is not None:
+        # large rings: points in a band around the camera circle's inside, so that a camera sees the points near its
+        # own azimuth from a sane distance (a unit blob in the middle of a 1778-camera ring would be seen by everybody)
+        azp = rng.uniform(0.0, 2 * np.pi, n_points)
+        rad = radius - rng.uniform(*point_radius, n_points)
+        ring_points = np.stack([rad * np.sin(azp), rng.normal(0, 0.3, n_points), -rad * np.cos(azp)], axis=1)
     fj = 1.0 + rng.uniform(-focal_jitter, focal_jitter, n_cams)
     cam_intr = np.stack([K[0] * fj, K[1] * fj, np.full(n_cams, K[2]), np.full(n_cams, K[3])], axis=1)
     n_obs_pts = n_points - n_unobserved
-    points_gt = rng.normal(0.0, 0.45, size=(n_points, 3))
+    points_gt = rng.normal(0.0, 0.45, size=(n_points, 3)) if point_radius is None else ring_points
     if visibility == "dense":
         n_obs = int(round(mean_track * n_obs_pts))
         L = _track_lengths(rng, n_obs_pts, n_obs, max_track=min(n_cams, max_track))
         L[:n_landmarks] = n_cams
         # window centred on the camera nearest to the point's azimuth
         az = np.arctan2(points_gt[:n_obs_pts, 0], -points_gt[:n_obs_pts, 2])
-        near = np.argmin(np.abs(((az[:, None] - ang[None, :] + np.pi) % (2 * np.pi)) - np.pi), axis=1)
+        if n_cams > 64:   # (cameras are evenly spaced on the full circle: nearest by rounding, no Np x Nc table)
+            near = np.rint((az % (2 * np.pi)) / (2 * np.pi) * n_cams).astype(np.int64) % n_cams
+        else:
+            near = np.argmin(np.abs(((az[:, None] - ang[None, :] + np.pi) % (2 * np.pi)) - np.pi), axis=1)
         start = near - L // 2
         obs_pt = np.repeat(np.arange(n_obs_pts, dtype=np.int64), L)
         first = np.cumsum(L) - L
@@ -188,9 +197,47 @@ def make_config(name, seed=None, scale=1.0):
     if name in ("temple", "C2"):
         return make_ring(47, int(20467 * scale), seed=1236 if seed is None else seed, focal_jitter=0.02,
                          noise=0.35, mean_track=4.0, n_fixed=1)
+    if name == "ring1778_loop":
+        # NOT banded: the Ladybug-sized camera count on a closed ring (camera 1777 sees what camera 0 sees: loop closure)
+        # with tracks of up to 40 cameras -- the reduced camera system has no small bandwidth in any camera order, so
+        # the solve goes through the block-Jacobi PCG (bench.py reports its LM iterations/s and PCG iterations)
+        return make_ring(1778, int(150000 * scale), seed=1239 if seed is None else seed, K=(1200.0, 1200.0, 960.0, 540.0),
+                         focal_jitter=0.05, noise=0.5, outlier_frac=0.01, mean_track=8.0, max_track=40, n_fixed=2,
+                         radius=283.0, point_radius=(4.0, 30.0), sig_t=2e-2, sig_p=5e-2)
     if name in SHAPES:
         nc, np_, no = SHAPES[name]
         idx = {"ladybug1723": 3, "venice1778": 4, "city10k": 5}[name]
         return make_street(nc, max(int(np_ * scale), 16), max(int(no * scale), 32),
                            seed=1233 + idx if seed is None else seed)
     raise ValueError(f"unknown config {name!r}")
+
+
+class KeyPoint:
+    """Stand-in for ``cv2.KeyPoint``: the path only reads ``.pt`` (``BundleAdjustment.py:269``)."""
+    __slots__ = ("pt",)
+
+    def __init__(self, x, y):
+        self.pt = (float(x), float(y))
+
+
+def to_image_data(prob, ids=None):
+    """A SoA problem as the containers the reference's driver holds (``Reconstruction.py:59-60``):
+    ``image_data[id] = (R, t (3,1), K, ref list (-1 = none), descriptors, keypoints)`` and ``[[x, y, z, r, g, b], ...]``.
+    Returns (visited_ids, image_data, all_points_3D)."""
+    n_c = len(prob["cam_pose"])
+    ids = list(range(n_c)) if ids is None else list(ids)
+    R = rvec_to_matrix(prob["cam_pose"][:, :3])
+    order = np.argsort(prob["obs_cam"], kind="stable")
+    oc, op, oxy = prob["obs_cam"][order], prob["obs_pt"][order], prob["obs_xy"][order]
+    start = np.searchsorted(oc, np.arange(n_c + 1))
+    image_data = {}
+    for i, cid in enumerate(ids):
+        fx, fy, cx, cy = prob["cam_intr"][i]
+        K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
+        a, b = start[i], start[i + 1]
+        kp = [KeyPoint(x, y) for x, y in oxy[a:b]]
+        ref = [int(v) for v in op[a:b]]
+        image_data[cid] = (R[i].copy(), prob["cam_pose"][i, 3:].reshape(3, 1).copy(), K, ref,
+                           np.zeros((len(kp), 1), np.float32), kp)
+    pts = [[float(x), float(y), float(z), 0.5, 0.5, 0.5] for x, y, z in prob["points"]]
+    return ids, image_data, pts

@@ -103,8 +103,8 @@ def engine_nccl_single_rank(rank, world, port, out_dir):
     p = synthetic.make_ring(16, 600, seed=8, mean_track=4.0, outlier_frac=0.02)
     sh, pidx = badist.shard_points(p, 0, 1)
     out = {}
-    for name, ordered in (("blocking", False), ("ordered", True)):
-        h = badist.create_sharded_handle(sh, 0, 1, stream_ordered=ordered, force_collectives=True, loss="huber",
+    for name, ordered, native in (("blocking", False, False), ("ordered", True, False), ("native", True, True)):
+        h = badist.create_sharded_handle(sh, 0, 1, stream_ordered=ordered, force_collectives=True, native=native, loss="huber",
                                          f_scale=1.0, max_iter=80, device=0)
         ms_pass, _ = h.build_bench(1e-4, warmup=2, reps=20)          # back-to-back passes, collectives in between
         s = h.run()
@@ -113,4 +113,28 @@ def engine_nccl_single_rank(rank, world, port, out_dir):
         out[name + "_cost"], out[name + "_status"], out[name + "_ms"] = s["final_cost"], s["status"], ms_pass
         h.close()
     np.savez(os.path.join(out_dir, "nccl1.npz"), **out)
+    dist.destroy_process_group()
+
+
+def engine_sharded_empty_rank(rank, world, port, out_dir):
+    """GPU, two ranks on one device: every camera anchored and ALL observed points on rank 0 -- rank 1 owns unobserved
+    points only and has nothing to optimise, but must stay in step with rank 0's collectives (it used to leave the LM
+    loop on its own: deadlock), and both must report the WHOLE problem's cost and residual sum."""
+    import torch
+    dist = _init(rank, world, port)
+    torch.cuda.set_device(0)
+    from structure_from_motion_amd import synthetic
+    from structure_from_motion_amd import dist as badist
+    p = synthetic.make_street(6, 60, 260, seed=3, outlier_frac=0.02)
+    fixed = np.ones(6, np.uint8)
+    if rank == 0:
+        sh = dict(p, cam_fixed=fixed)
+    else:
+        sh = dict(cam_pose=p["cam_pose"], cam_intr=p["cam_intr"], cam_fixed=fixed, points=np.ones((5, 3)),
+                  obs_cam=np.zeros(0, np.int32), obs_pt=np.zeros(0, np.int32), obs_xy=np.zeros((0, 2)))
+    h = badist.create_sharded_handle(sh, rank, world, loss="huber", f_scale=1.0, max_iter=40, device=0)
+    s = h.run()
+    np.savez(os.path.join(out_dir, f"empty{rank}.npz"), cost=s["final_cost"], rsum=s["residual_sum"], status=s["status"],
+             iters=s["iterations"], cost0=s["initial_cost"])
+    h.close()
     dist.destroy_process_group()

@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 import torch.multiprocessing as mp
-from dist_workers import engine_nccl_single_rank, engine_sharded_solve
+from dist_workers import engine_nccl_single_rank, engine_sharded_empty_rank, engine_sharded_solve
 from test_dist_cpu import _free_port
 
 from structure_from_motion_amd import _capi, synthetic
@@ -36,8 +36,24 @@ def test_rccl_callbacks_blocking_and_stream_ordered(gpu, tmp_path):
     p = synthetic.make_ring(16, 600, seed=8, mean_track=4.0, outlier_frac=0.02)
     arr = _capi.Arrays.from_dict(p)
     s = _capi.solve(arr, loss="huber", f_scale=1.0, max_iter=80)
-    for name in ("blocking", "ordered"):
+    for name in ("blocking", "ordered", "native"):   # native = the library's own RCCL binding (ba_rccl_init), no Python in the loop
         assert int(r[name + "_status"]) == s["status"]
         assert abs(float(r[name + "_cost"]) - s["final_cost"]) <= 1e-9 * s["final_cost"]
         assert np.allclose(r[name + "_cp"], arr.cam_pose, atol=1e-6) and np.allclose(r[name + "_pts"], arr.points, atol=1e-5)
-    print("build pass with collectives: blocking %.3f ms, stream-ordered %.3f ms" % (float(r["blocking_ms"]), float(r["ordered_ms"])))
+    print("build pass with collectives: blocking %.3f ms, stream-ordered %.3f ms, library-side RCCL %.3f ms"
+          % (float(r["blocking_ms"]), float(r["ordered_ms"]), float(r["native_ms"])))
+
+
+def test_rank_without_observations_stays_in_step(gpu, tmp_path):
+    mp.spawn(engine_sharded_empty_rank, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "empty0.npz"), np.load(tmp_path / "empty1.npz")
+    p = synthetic.make_street(6, 60, 260, seed=3, outlier_frac=0.02)
+    p["cam_fixed"] = np.ones(6, np.uint8)
+    arr = _capi.Arrays.from_dict(p)
+    s = _capi.solve(arr, loss="huber", f_scale=1.0, max_iter=40)
+    for r in (r0, r1):
+        assert int(r["status"]) == s["status"] and int(r["iters"]) == s["iterations"]
+        assert abs(float(r["cost"]) - s["final_cost"]) <= 1e-9 * s["final_cost"]
+        assert abs(float(r["cost0"]) - s["initial_cost"]) <= 1e-12 * s["initial_cost"]
+        assert abs(float(r["rsum"]) - s["residual_sum"]) <= 1e-7 * max(1.0, abs(s["residual_sum"]))
+    assert float(r0["cost"]) == float(r1["cost"]) and float(r0["rsum"]) == float(r1["rsum"])
