@@ -101,6 +101,31 @@ def other_configs(_capi, synthetic):
             out["temple_final_ba"][name.replace("wall_ms", "ok")] = bool(ok)
     except Exception as e:  # never lose the headline line over a side measurement
         out["temple_final_ba"]["host_api_error"] = repr(e)
+    # f1: the incremental driver's growth (Fountain-shaped, visibility as Reconstruction.py records it): the problem with
+    # 9 of its 11 images resident, then the last two images and their points arrive -- ba_append against a new handle
+    try:
+        import numpy as np
+        p = synthetic.make_config("fountain_sfm")
+        m = p["obs_cam"] < 9
+        npts = int(p["obs_pt"][m].max()) + 1
+        first = dict(cam_pose=p["cam_pose"][:9], cam_intr=p["cam_intr"][:9], cam_fixed=p["cam_fixed"][:9], points=p["points"][:npts],
+                     obs_cam=p["obs_cam"][m], obs_pt=p["obs_pt"][m], obs_xy=p["obs_xy"][m])
+        assert np.all(p["obs_pt"][~m] >= npts)
+        with _capi.Handle(_capi.Arrays.from_dict(first), loss="huber", f_scale=1.5, max_iter=150) as h:
+            h.run()
+            t0 = time.perf_counter()
+            appended = h.append(_capi.Arrays.from_dict(p))
+            t_app = (time.perf_counter() - t0) * 1e3
+            s_app = h.run()
+        t0 = time.perf_counter()
+        with _capi.Handle(_capi.Arrays.from_dict(p), loss="huber", f_scale=1.5, max_iter=150) as h2:
+            t_new = (time.perf_counter() - t0) * 1e3
+            s_new = h2.run()
+        out["fountain_incremental"] = {"observations": [int(m.sum()), len(m)], "appended_in_place": bool(appended),
+                                       "append_ms": t_app, "new_handle_ms": t_new,
+                                       "cost_after": [s_app["final_cost"], s_new["final_cost"]]}
+    except Exception as e:
+        out["fountain_incremental"] = {"error": repr(e)}
     p = synthetic.make_config("ladybug1723")
     with _capi.Handle(_capi.Arrays.from_dict(p), loss="huber", f_scale=1.0, max_iter=300) as h:
         h.build_bench(1e-4, warmup=0, reps=3)

@@ -197,6 +197,18 @@ int ba_build_bench(BaHandle *h, double lambda, int32_t warmup, int32_t reps, dou
  * LM state starts afresh.  Skips the symbolic analysis, every allocation and the index uploads of ba_create: what
  * the reference's repeated inter_ba calls over an unchanged track set (sfm.py:184-191, 252-258) would re-pay. */
 int ba_set_values(BaHandle *h, const BaProblem *prob, const BaOptions *opt);
+/* f1, the incremental driver's pattern (inter_ba every second image on a GROWING problem, Reconstruction.py:244-255,
+ * marshalling BundleAdjustment.py:243-306): `grown` is the handle's problem with cameras, points and observations
+ * added at the END of its arrays (the old ones are a prefix: same gauge, same (camera, point) per old observation --
+ * checked); all values are taken from `grown`, the LM state starts afresh, opt (NULL = keep) as in ba_set_values.
+ *   *mode = 1  appended: the new observations only see points nobody saw before (what the reference's driver records:
+ *              a new image's points are its own).  Only those points are analysed; their chunks, pair entries and index
+ *              arrays are appended behind the old ones on the host and in HBM (the resident arrays grow in place,
+ *              re-allocated geometrically), old block slots keep their numbers.
+ *   *mode = 0  rebuilt inside the handle: an old track grew, a long-track ("heavy") point is involved, or the prefix
+ *              rule does not hold (e.g. the gauge changed at 15 images, BundleAdjustment.py:38).  Same result, full analysis.
+ * Not for sharded handles (BA_ERR_UNSUPPORTED); a shrunken problem is BA_ERR_INVALID.  mode may be NULL. */
+int ba_append(BaHandle *h, const BaProblem *grown, const BaOptions *opt, int32_t *mode);
 /* Up to max_steps LM trial steps (continues from the current state); fills *out. */
 int ba_run(BaHandle *h, int32_t max_steps, BaSummary *out);
 int ba_get_state(BaHandle *h, double *cam_pose, double *points); /* host pointers, caller's order */

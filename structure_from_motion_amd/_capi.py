@@ -25,7 +25,7 @@ EXPORTED = [
     "ba_get_pattern", "ba_set_pattern", "ba_set_collective", "ba_build", "ba_build_bench", "ba_run",
     "ba_get_state", "ba_get_cost", "ba_get_reduced_system", "ba_get_reduced_blocks", "ba_synchronize",
     "ba_set_values", "ba_set_collective_mode", "ba_get_stream", "ba_eval_cost_noalloc",
-    "ba_eval_reprojection_errors_rt", "ba_get_reprojection_errors", "ba_rccl_unique_id", "ba_rccl_init",
+    "ba_eval_reprojection_errors_rt", "ba_get_reprojection_errors", "ba_rccl_unique_id", "ba_rccl_init", "ba_append",
 ]
 
 
@@ -120,6 +120,7 @@ def load():
     lib.ba_set_collective_mode.argtypes = [C.c_void_p, C.c_int32]
     lib.ba_get_stream.argtypes = [C.c_void_p, P(C.c_void_p)]
     lib.ba_set_values.argtypes = [C.c_void_p, P(BaProblem), P(BaOptions)]
+    lib.ba_append.argtypes = [C.c_void_p, P(BaProblem), P(BaOptions), P(C.c_int32)]
     for name in EXPORTED:
         if name not in ("ba_last_error", "ba_default_options", "ba_create", "ba_destroy"):
             getattr(lib, name).restype = C.c_int
@@ -278,6 +279,17 @@ class Handle:
             self.opts = default_options(**opts)
         check(self._lib.ba_set_values(self.h, C.byref(arr.struct), C.byref(self.opts) if opts else None))
         self.arr = arr
+
+    def append(self, arr, **opts):
+        """The handle's problem GROWN at the end of its arrays (``ba_append``): new cameras / points / observations,
+        all values from ``arr``.  Returns True when the new part was appended to the resident structure, False when
+        the structure had to be rebuilt inside the handle (same result either way)."""
+        if opts:
+            self.opts = default_options(**opts)
+        mode = C.c_int32(0)
+        check(self._lib.ba_append(self.h, C.byref(arr.struct), C.byref(self.opts) if opts else None, C.byref(mode)))
+        self.arr = arr
+        return mode.value == 1
 
     def build(self, lam=1e-4):
         check(self._lib.ba_build(self.h, float(lam)))

@@ -65,7 +65,7 @@ int fail(int code, const char *fmt, ...) {
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
-    size_t n = 0;
+    size_t n = 0, cap = 0;
     ~DevBuf() { release(); }
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
@@ -73,13 +73,34 @@ struct DevBuf {
     void release() {
         if (p) (void)hipFree(p);
         p = nullptr;
-        n = 0;
+        n = cap = 0;
     }
     hipError_t alloc(size_t count) {
         release();
         n = count;
         if (count == 0) count = 1;
+        cap = count;
         return hipMalloc((void **)&p, count * sizeof(T));
+    }
+    // ba_append: new elements behind the first `keep` ones, which stay where they are in HBM.  The allocation grows
+    // geometrically (device-to-device copy of the kept part) so that a sequence of appends re-allocates rarely.
+    hipError_t append_at(size_t keep, const T *tail, size_t count) {
+        if (keep > n) keep = n;
+        const size_t need = keep + count;
+        if (!p || need > cap) {
+            const size_t ncap = need + need / 2 + 64;
+            T *q = nullptr;
+            hipError_t e = hipMalloc((void **)&q, ncap * sizeof(T));
+            if (e != hipSuccess) return e;
+            if (p && keep) e = hipMemcpy(q, p, keep * sizeof(T), hipMemcpyDeviceToDevice);
+            if (p) (void)hipFree(p);
+            p = q;
+            cap = ncap;
+            if (e != hipSuccess) return e;
+        }
+        n = need;
+        if (count == 0) return hipSuccess;
+        return hipMemcpy(p + keep, tail, count * sizeof(T), hipMemcpyHostToDevice);
     }
     // (a BLOCKING copy: the sources of these one-time uploads are often temporaries that die before the stream is
     // synchronised, and HIP does not promise that a pageable-memory hipMemcpyAsync has read its source on return)
@@ -599,6 +620,74 @@ int check_options(BaOptions &o) {
     return BA_OK;
 }
 
+// work buffers whose sizes follow the structure (no contents to keep): called after the structure (re)build
+int alloc_work(BaHandle *h) {
+    const Symbolic &s = h->sym;
+    const int nf = s.n_free;
+    for (int b = 0; b < 2; ++b) HIPCHK(h->aux[b].alloc((size_t)s.n_cams * BA_CAM_AUX));
+    HIPCHK(h->Minv.alloc((size_t)nf * 36));
+    HIPCHK(h->cam_gmax.alloc((size_t)nf));
+    HIPCHK(h->gm2.alloc(2));
+    HIPCHK(h->pt_linv.alloc((size_t)s.n_pts_obs * 6));
+    HIPCHK(h->pt_u.alloc((size_t)s.n_pts_obs * 3));
+    HIPCHK(h->ck_cost.alloc((size_t)(h->n_chunks + h->n_heavy)));
+    HIPCHK(h->ck_gmax.alloc((size_t)(h->n_chunks + h->n_heavy)));
+    HIPCHK(h->ck_part.alloc((size_t)(h->n_chunks + h->n_heavy) * 4));
+    HIPCHK(h->cam_part.alloc((size_t)s.n_cams * 2));
+    HIPCHK(h->step_sums.alloc(4));
+    HIPCHK(h->cam_sums.alloc(2));
+    HIPCHK(h->px.alloc((size_t)nf * 6));
+    HIPCHK(h->pr.alloc((size_t)nf * 6));
+    HIPCHK(h->pz.alloc((size_t)nf * 6));
+    HIPCHK(h->pp.alloc((size_t)nf * 6));
+    HIPCHK(h->pq.alloc((size_t)nf * 6));
+    HIPCHK(h->pqv.alloc((size_t)nf * 6));
+    HIPCHK(h->pcg_sc.alloc(1));
+    HIPCHK(h->state.alloc(1));
+    // solver work space is sized on first use: drop what belonged to another structure
+    h->dense_a.release();
+    h->band_l.release(); h->band_y.release(); h->band_g.release(); h->band_mid.release();
+    h->dbg_v.release(); h->dbg_gp.release();
+    h->pattern_uploaded = false;
+    return BA_OK;
+}
+
+// whole structure of a problem: symbolic analysis on the host, every index array to the device
+int build_structure(BaHandle *h, const HostProblem &hp, int n_cams, int n_points, int64_t n_obs) {
+    int e;
+    const char *msg = "";
+    if ((e = analyze_structure(n_cams, n_points, n_obs, hp.cam_fixed.data(), hp.obs_cam.data(), hp.obs_pt.data(), h->sym, &msg)))
+        return fail(e, "%s", msg);
+    finalize_pattern(h->sym, {});
+    Symbolic &s = h->sym;
+    hipStream_t st = h->stream;
+    h->n_chunks = (int)s.ck_obs.size() - 1;
+    h->n_heavy = s.n_heavy;
+    if (s.n_heavy > 0) {
+        std::vector<long long> ho(s.hv_obs.begin(), s.hv_obs.end()), hq(s.hv_pair.begin(), s.hv_pair.end());
+        HIPCHK(h->hv_obs.upload(ho, st));
+        HIPCHK(h->hv_pair.upload(hq, st));
+        HIPCHK(h->hv_t.alloc((size_t)(s.hv_obs.back() - s.hv_obs.front()) * 18));
+    }
+    HIPCHK(h->cam_free.upload(s.cam_free, st));
+    HIPCHK(h->free_cam.upload(s.free_cam, st));
+    HIPCHK(h->o_cam.upload(s.o_cam, st));
+    HIPCHK(h->o_pt.upload(s.o_pt, st));
+    HIPCHK(h->o_lcam.upload(s.o_lcam, st));
+    HIPCHK(h->ck_obs.upload(s.ck_obs, st));
+    HIPCHK(h->ck_pt.upload(s.ck_pt, st));
+    HIPCHK(h->ck_cam.upload(s.ck_cam, st));
+    HIPCHK(h->ck_cam_list.upload(s.ck_cam_list, st));
+    HIPCHK(h->ck_pair.upload(s.ck_pair, st));
+    {
+        std::vector<long long> pe(s.ck_pe.begin(), s.ck_pe.end());
+        HIPCHK(h->ck_pe.upload(pe, st));
+    }
+    HIPCHK(h->pair_entries.upload(s.pair_entries, st));
+    HIPCHK(h->ck_pgrp.upload(s.ck_pgrp, st));
+    return alloc_work(h);
+}
+
 int create_impl(const BaProblem *prob, const BaOptions *opt, BaHandle *h) {
     const double t0 = now_ms();
     int e = validate(prob);
@@ -619,60 +708,110 @@ int create_impl(const BaProblem *prob, const BaOptions *opt, BaHandle *h) {
     HIPCHK(hipEventCreate(&h->ev3));
     HostProblem hp;
     if ((e = fetch_problem(prob, hp, false))) return e;
-    const char *msg = "";
-    if ((e = analyze_structure(prob->n_cams, prob->n_points, prob->n_obs, hp.cam_fixed.data(), hp.obs_cam.data(),
-                               hp.obs_pt.data(), h->sym, &msg)))
-        return fail(e, "%s", msg);
-    finalize_pattern(h->sym, {});
-    Symbolic &s = h->sym;
-    hipStream_t st = h->stream;
-    h->n_chunks = (int)s.ck_obs.size() - 1;
-    h->n_heavy = s.n_heavy;
-    if (s.n_heavy > 0) {
-        std::vector<long long> ho(s.hv_obs.begin(), s.hv_obs.end()), hq(s.hv_pair.begin(), s.hv_pair.end());
-        HIPCHK(h->hv_obs.upload(ho, st));
-        HIPCHK(h->hv_pair.upload(hq, st));
-        HIPCHK(h->hv_t.alloc((size_t)(s.hv_obs.back() - s.hv_obs.front()) * 18));
-    }
-    for (int b = 0; b < 2; ++b) HIPCHK(h->aux[b].alloc((size_t)s.n_cams * BA_CAM_AUX));
-    HIPCHK(h->cam_free.upload(s.cam_free, st));
-    HIPCHK(h->free_cam.upload(s.free_cam, st));
-    HIPCHK(h->o_cam.upload(s.o_cam, st));
-    HIPCHK(h->o_pt.upload(s.o_pt, st));
-    HIPCHK(h->o_lcam.upload(s.o_lcam, st));
-    HIPCHK(h->ck_obs.upload(s.ck_obs, st));
-    HIPCHK(h->ck_pt.upload(s.ck_pt, st));
-    HIPCHK(h->ck_cam.upload(s.ck_cam, st));
-    HIPCHK(h->ck_cam_list.upload(s.ck_cam_list, st));
-    HIPCHK(h->ck_pair.upload(s.ck_pair, st));
-    {
-        std::vector<long long> pe(s.ck_pe.begin(), s.ck_pe.end());
-        HIPCHK(h->ck_pe.upload(pe, st));
-    }
-    HIPCHK(h->pair_entries.upload(s.pair_entries, st));
-    HIPCHK(h->ck_pgrp.upload(s.ck_pgrp, st));
-    const int nf = s.n_free;
-    HIPCHK(h->Minv.alloc((size_t)nf * 36));
-    HIPCHK(h->cam_gmax.alloc((size_t)nf));
-    HIPCHK(h->gm2.alloc(2));
-    HIPCHK(h->pt_linv.alloc((size_t)s.n_pts_obs * 6));
-    HIPCHK(h->pt_u.alloc((size_t)s.n_pts_obs * 3));
-    HIPCHK(h->ck_cost.alloc((size_t)(h->n_chunks + h->n_heavy)));
-    HIPCHK(h->ck_gmax.alloc((size_t)(h->n_chunks + h->n_heavy)));
-    HIPCHK(h->ck_part.alloc((size_t)(h->n_chunks + h->n_heavy) * 4));
-    HIPCHK(h->cam_part.alloc((size_t)s.n_cams * 2));
-    HIPCHK(h->step_sums.alloc(4));
-    HIPCHK(h->cam_sums.alloc(2));
-    HIPCHK(h->px.alloc((size_t)nf * 6));
-    HIPCHK(h->pr.alloc((size_t)nf * 6));
-    HIPCHK(h->pz.alloc((size_t)nf * 6));
-    HIPCHK(h->pp.alloc((size_t)nf * 6));
-    HIPCHK(h->pq.alloc((size_t)nf * 6));
-    HIPCHK(h->pqv.alloc((size_t)nf * 6));
-    HIPCHK(h->pcg_sc.alloc(1));
-    HIPCHK(h->state.alloc(1));
+    if ((e = build_structure(h, hp, prob->n_cams, prob->n_points, prob->n_obs))) return e;
     if ((e = upload_values(h, hp))) return e;
     h->t_setup_ms = now_ms() - t0;
+    return BA_OK;
+}
+
+// ba_append, fast path: the grown problem differs from the handle's by new cameras, new points and new observations
+// that only see points nobody saw before (what the reference's driver produces, Reconstruction.py:244-251).  Then the
+// old chunks, their pair entries and their block slots are all still valid: only the new points are analysed (as a
+// problem of their own), and their chunks are appended behind the old ones, on the host and in HBM.
+// Returns BA_OK with *done = false when the pattern does not apply (the caller rebuilds everything).
+int append_tail(BaHandle *h, const HostProblem &hp, int nc2, int np2, int64_t no2, bool *done) {
+    *done = false;
+    Symbolic &s = h->sym;
+    const int64_t no1 = s.n_obs;
+    if (s.n_heavy > 0 || no2 == no1) return BA_OK;
+    // points seen before (by the handle's observations)
+    std::vector<uint8_t> seen((size_t)np2, 0);
+    for (int i = 0; i < s.n_pts_obs; ++i) seen[s.pt_order[i]] = 1;
+    std::vector<int32_t> local((size_t)np2, -1), tail_pts;
+    for (int64_t k = no1; k < no2; ++k) {
+        const int32_t p = hp.obs_pt[k];
+        if (p < 0 || p >= np2 || hp.obs_cam[k] < 0 || hp.obs_cam[k] >= nc2) return fail(BA_ERR_INVALID, "observation index out of range");
+        if (seen[p]) return BA_OK;   // an old track grew: its chunk changes
+        if (local[p] < 0) { local[p] = 0; tail_pts.push_back(p); }
+    }
+    std::sort(tail_pts.begin(), tail_pts.end());
+    for (size_t i = 0; i < tail_pts.size(); ++i) local[tail_pts[i]] = (int32_t)i;
+    std::vector<int32_t> t_cam(hp.obs_cam.begin() + no1, hp.obs_cam.begin() + no2), t_pt((size_t)(no2 - no1));
+    for (int64_t k = no1; k < no2; ++k) t_pt[k - no1] = local[hp.obs_pt[k]];
+    Symbolic t;
+    const char *msg = "";
+    int e;
+    if ((e = analyze_structure(nc2, (int)tail_pts.size(), no2 - no1, hp.cam_fixed.data(), t_cam.data(), t_pt.data(), t, &msg)))
+        return fail(e, "%s", msg);
+    if (t.n_heavy > 0) return BA_OK;
+    // ---- merge the tail into the handle's structure ----
+    const int P1 = s.n_pts_chunked, nck1 = (int)s.ck_obs.size() - 1;
+    const size_t pad = (size_t)(CHUNK_OBS / 2) * PAIR_RUN;
+    const size_t pe1 = (size_t)s.ck_pe.back(), cl1 = s.ck_cam_list.size(), rk1 = s.raw_keys.size(), pg1 = s.ck_pgrp.size();
+    s.n_cams = nc2; s.n_points = np2; s.n_obs = no2;
+    s.cam_free = t.cam_free; s.free_cam = t.free_cam; s.n_free = t.n_free;
+    {
+        std::vector<int32_t> order;
+        order.reserve((size_t)np2);
+        order.insert(order.end(), s.pt_order.begin(), s.pt_order.begin() + P1);
+        for (int i = 0; i < t.n_pts_chunked; ++i) order.push_back(tail_pts[t.pt_order[i]]);
+        for (int i = 0; i < P1; ++i) seen[s.pt_order[i]] = 1;
+        for (int32_t p : tail_pts) seen[p] = 1;
+        for (int p = 0; p < np2; ++p)
+            if (!seen[p]) order.push_back(p);   // unobserved points last, in index order
+        s.pt_order.swap(order);
+    }
+    s.n_pts_chunked = s.n_pts_obs = P1 + t.n_pts_chunked;
+    s.o_cam.insert(s.o_cam.end(), t.o_cam.begin(), t.o_cam.end());
+    s.o_lcam.insert(s.o_lcam.end(), t.o_lcam.begin(), t.o_lcam.end());
+    for (int32_t v : t.o_pt) s.o_pt.push_back(v + P1);
+    for (int64_t v : t.obs_order) s.obs_order.push_back(no1 + v);
+    for (size_t c = 1; c < t.ck_obs.size(); ++c) {
+        s.ck_obs.push_back(t.ck_obs[c] + (int32_t)no1);
+        s.ck_pt.push_back(t.ck_pt[c] + P1);
+        s.ck_cam.push_back(t.ck_cam[c] + (int32_t)cl1);
+        s.ck_pair.push_back(t.ck_pair[c] + (int32_t)rk1);
+        s.ck_pe.push_back(t.ck_pe[c] + (int64_t)pe1);
+    }
+    s.ck_cam_list.insert(s.ck_cam_list.end(), t.ck_cam_list.begin(), t.ck_cam_list.end());
+    s.raw_keys.insert(s.raw_keys.end(), t.raw_keys.begin(), t.raw_keys.end());
+    s.ck_pair_slot.resize(s.raw_keys.size(), -1);
+    s.ck_pgrp.insert(s.ck_pgrp.end(), t.ck_pgrp.begin(), t.ck_pgrp.end());
+    s.pair_entries.resize(pe1);                                   // (drop the old read-ahead padding; the tail brings its own)
+    s.pair_entries.insert(s.pair_entries.end(), t.pair_entries.begin(), t.pair_entries.end());
+    s.n_pair_real += t.n_pair_real;
+    s.n_direct_pairs += t.n_direct_pairs;
+    s.n_direct_cam_obs += t.n_direct_cam_obs;
+    s.max_track = std::max(s.max_track, t.max_track);
+    s.max_chunk_cams = std::max(s.max_chunk_cams, t.max_chunk_cams);
+    s.max_chunk_pairs = std::max(s.max_chunk_pairs, t.max_chunk_pairs);
+    s.mean_track = s.n_pts_obs ? (double)no2 / s.n_pts_obs : 0.0;
+    s.hv_obs.assign(1, no2);
+    s.hv_pair.assign(1, 0);
+    finalize_pattern(s, {});   // new keys only involve new cameras when the gauge is unchanged: old slots keep their numbers
+    (void)pad;
+    // ---- device: the old index arrays stay where they are, the tails go behind them ----
+    h->n_chunks = (int)s.ck_obs.size() - 1;
+    h->n_heavy = 0;
+    HIPCHK(h->cam_free.upload(s.cam_free, h->stream));
+    HIPCHK(h->free_cam.upload(s.free_cam, h->stream));
+    HIPCHK(h->o_cam.append_at((size_t)no1, t.o_cam.data(), t.o_cam.size()));
+    HIPCHK(h->o_pt.append_at((size_t)no1, s.o_pt.data() + no1, t.o_pt.size()));
+    HIPCHK(h->o_lcam.append_at((size_t)no1, t.o_lcam.data(), t.o_lcam.size()));
+    const size_t ntc = t.ck_obs.size() - 1;
+    HIPCHK(h->ck_obs.append_at((size_t)nck1 + 1, s.ck_obs.data() + nck1 + 1, ntc));
+    HIPCHK(h->ck_pt.append_at((size_t)nck1 + 1, s.ck_pt.data() + nck1 + 1, ntc));
+    HIPCHK(h->ck_cam.append_at((size_t)nck1 + 1, s.ck_cam.data() + nck1 + 1, ntc));
+    HIPCHK(h->ck_pair.append_at((size_t)nck1 + 1, s.ck_pair.data() + nck1 + 1, ntc));
+    {
+        std::vector<long long> pe(s.ck_pe.begin() + nck1 + 1, s.ck_pe.end());
+        HIPCHK(h->ck_pe.append_at((size_t)nck1 + 1, pe.data(), pe.size()));
+    }
+    HIPCHK(h->ck_cam_list.append_at(cl1, t.ck_cam_list.data(), t.ck_cam_list.size()));
+    HIPCHK(h->ck_pgrp.append_at(pg1, t.ck_pgrp.data(), t.ck_pgrp.size()));
+    HIPCHK(h->pair_entries.append_at(pe1, t.pair_entries.data(), t.pair_entries.size()));
+    if ((e = alloc_work(h))) return e;
+    *done = true;
     return BA_OK;
 }
 
@@ -808,6 +947,51 @@ int ba_set_values(BaHandle *h, const BaProblem *prob, const BaOptions *opt) {
         return BA_OK;
     } catch (const std::bad_alloc &) {
         return fail(BA_ERR_NOMEM, "out of host memory");
+    }
+}
+
+int ba_append(BaHandle *h, const BaProblem *grown, const BaOptions *opt, int32_t *mode) {
+    if (!h) return fail(BA_ERR_INVALID, "null handle");
+    if (mode) *mode = 0;
+    const double t0 = now_ms();
+    int e = validate(grown);
+    if (e) return e;
+    Symbolic &s = h->sym;
+    if (grown->n_cams < s.n_cams || grown->n_points < s.n_points || grown->n_obs < s.n_obs)
+        return fail(BA_ERR_INVALID, "ba_append: the problem shrank (%d cameras, %d points, %lld observations against the handle's %d, %d, %lld)",
+                    grown->n_cams, grown->n_points, (long long)grown->n_obs, s.n_cams, s.n_points, (long long)s.n_obs);
+    if (h->coll) return fail(BA_ERR_UNSUPPORTED, "ba_append on a sharded handle (the ranks would have to agree on a new pattern)");
+    BaOptions o = h->opt;
+    if (opt) {
+        o = *opt;
+        o.device = h->opt.device;
+        if ((e = check_options(o))) return e;
+    }
+    (void)hipSetDevice(h->device);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    try {
+        HostProblem hp;
+        if ((e = fetch_problem(grown, hp, false))) return e;
+        // the handle's problem must be a prefix of the grown one: same gauge for the old cameras, same (camera, point) for
+        // every old observation
+        bool prefix = true;
+        for (int c = 0; c < s.n_cams && prefix; ++c) prefix = (hp.cam_fixed[c] != 0) == (s.cam_free[c] < 0);
+        for (int64_t k = 0; k < s.n_obs && prefix; ++k) {
+            const int64_t src = s.obs_order[k];
+            prefix = hp.obs_cam[src] == s.o_cam[k] && hp.obs_pt[src] == s.pt_order[s.o_pt[k]];
+        }
+        bool appended = false;
+        if (prefix && (e = append_tail(h, hp, grown->n_cams, grown->n_points, grown->n_obs, &appended))) return e;
+        if (!appended && (e = build_structure(h, hp, grown->n_cams, grown->n_points, grown->n_obs))) return e;
+        h->opt = o;
+        if ((e = upload_values(h, hp))) return e;
+        if (mode) *mode = appended ? 1 : 0;
+        h->t_setup_ms = now_ms() - t0;
+        return BA_OK;
+    } catch (const std::bad_alloc &) {
+        return fail(BA_ERR_NOMEM, "out of host memory");
+    } catch (...) {
+        return fail(BA_ERR_INVALID, "unexpected exception in ba_append");
     }
 }
 

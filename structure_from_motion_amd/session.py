@@ -10,9 +10,12 @@ functions in ``BundleAdjustment.py`` of this package, which the tests compare it
 
 Device-resident reuse: the session keeps the engine handle of its last solve.  A call whose structure
 (camera set, gauge, (camera, point) of every observation) is the one the handle was analysed for goes through
-``ba_set_values`` -- values re-uploaded, no symbolic analysis, no allocation; any other call (the incremental
-driver's usual case: the track set grew) builds a new handle.  The C side compares the structures exactly, so a
-stale handle can never be used for another problem.  ``close()`` (or dropping the session) frees the handle.
+``ba_set_values`` -- values re-uploaded, no symbolic analysis, no allocation.  A call whose problem GREW (the
+incremental driver's usual case: images registered, points triangulated since the last call) goes through
+``ba_append``: when the new observations only see new points -- what the reference's driver records -- only those are
+analysed and their chunks are appended to the resident arrays; otherwise the structure is rebuilt inside the handle.
+The C side compares the structures exactly, so a stale handle can never be used for another problem.  ``close()``
+(or dropping the session) frees the handle.
 """
 import numpy as np
 
@@ -27,7 +30,8 @@ class BASession:
         self.last_summary = None
         self.reuse_device = reuse_device
         self._handle = None       # engine handle of the last solve (structure + device buffers)
-        self.handle_reuses = 0
+        self.handle_reuses = 0        # calls that went through ba_set_values / ba_append instead of a new handle
+        self.handle_appends = 0       # ... of which the resident structure was extended in place (ba_append, mode 1)
         self._resident = None     # what the handle's device state corresponds to on the host (see compute_ba_reprojection_errors)
         self.resident_error_calls = 0
 
@@ -41,18 +45,22 @@ class BASession:
         """ba_solve's sequence (create | set_values, run, get_state) on the session's handle; arr is updated in place."""
         h = self._handle
         if h is not None:
-            same = (h.arr.struct.n_cams, h.arr.struct.n_points, h.arr.struct.n_obs) == \
-                   (arr.struct.n_cams, arr.struct.n_points, arr.struct.n_obs)
-            if same:
-                try:
-                    h.set_values(arr, **opts)
+            old = (h.arr.struct.n_cams, h.arr.struct.n_points, h.arr.struct.n_obs)
+            new = (arr.struct.n_cams, arr.struct.n_points, arr.struct.n_obs)
+            try:
+                if old == new:
+                    h.set_values(arr, **opts)            # same structure (checked exactly on the C side): values only
                     self.handle_reuses += 1
-                except _capi.BaError as e:
-                    if e.code != _capi.BA_ERR_INVALID:
-                        raise
-                    same = False
-            if not same:
-                self.close()
+                elif all(n >= o for n, o in zip(new, old)):
+                    # the incremental driver's case: images were registered and points triangulated since the last call
+                    self.handle_appends += bool(h.append(arr, **opts))
+                    self.handle_reuses += 1
+                else:
+                    self.close()
+            except _capi.BaError as e:
+                if e.code != _capi.BA_ERR_INVALID:
+                    raise
+                self.close()                             # another problem altogether: a new handle
         if self._handle is None:
             self._handle = _capi.Handle(arr, **opts)
         h = self._handle

@@ -241,6 +241,38 @@ def test_incremental_driver_pattern(gpu):
     sess.close()
 
 
+def test_session_appends_on_a_growing_reconstruction(gpu):
+    """f1: the reference driver's loop on a reconstruction that GROWS the way Reconstruction.py:244-251 grows it (each
+    new image brings its own points).  Every inter_ba of the session after the first extends the resident structure
+    (ba_append) instead of building a new handle, and walks the states of the module functions."""
+    from structure_from_motion_amd.session import BASession
+    from structure_from_motion_amd import synthetic
+    from test_gpu_parity import _grow_h4
+    stages = _grow_h4(4, seed=3)
+    ids_all, image_full, pts_full = synthetic.to_image_data(stages[-1])
+    d1, d2 = {}, {}
+    p1 = p2 = None
+    sess = BASession()
+    for k, st in enumerate(stages):
+        ids = ids_all[:len(st["cam_pose"])]
+        for c in ids:
+            if c not in d1:
+                d1[c] = copy.deepcopy(image_full[c]); d2[c] = copy.deepcopy(image_full[c])
+        n_p = len(st["points"])
+        p1 = (p1 or []) + copy.deepcopy(pts_full[len(p1 or []):n_p])
+        p2 = (p2 or []) + copy.deepcopy(pts_full[len(p2 or []):n_p])
+        r1 = BA.inter_ba(d1, p1, ids, ba_interval=1, verbose=False)
+        r2 = sess.inter_ba(d2, p2, ids, ba_interval=1, verbose=False)
+        assert r1[2] == r2[2] is True
+        p1, p2 = r1[0], r2[0]
+        np.testing.assert_allclose(np.array(p2)[:, :3], np.array(p1)[:, :3], rtol=0, atol=1e-5)
+        for c in ids:
+            np.testing.assert_allclose(d2[c][0], d1[c][0], rtol=0, atol=1e-6)
+            np.testing.assert_allclose(d2[c][1], d1[c][1], rtol=0, atol=1e-5)
+    assert sess.handle_reuses == len(stages) - 1 and sess.handle_appends == len(stages) - 1
+    sess.close()
+
+
 def test_opt_in_point_culling(gpu):
     """SURVEY 8(f) f4 (opt-in, not reference behaviour): a grossly wrong observation un-references its point."""
     from structure_from_motion_amd.session import BASession

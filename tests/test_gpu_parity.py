@@ -323,6 +323,98 @@ def test_set_values_reuses_the_structure(gpu):
         assert abs(h.cost() - s1["final_cost"]) <= 1e-9 * s1["final_cost"]
 
 
+def _grow_h4(n_stages, seed=0):
+    """A problem that grows the way the reference's driver grows it (Reconstruction.py:244-251): stage k registers one
+    more camera and triangulates points that only the NEW image references; the seed pair's points are seen twice.
+    Returns the list of SoA problems (each one a prefix of the next in cameras / points / observations)."""
+    rng = np.random.default_rng(seed)
+    full = synthetic.make_ring(3 + n_stages, 700, seed=seed + 1, visibility="sfm", n_seed_points=120, n_fixed=2, noise=0.3)
+    out = []
+    for k in range(n_stages + 1):
+        nc = 3 + k
+        m = full["obs_cam"] < nc
+        npts = int(full["obs_pt"][m].max()) + 1 + int(rng.integers(0, 3))      # a few points nobody references yet
+        npts = min(npts, len(full["points"]))
+        out.append(dict(cam_pose=full["cam_pose"][:nc], cam_intr=full["cam_intr"][:nc], cam_fixed=full["cam_fixed"][:nc],
+                        points=full["points"][:npts], obs_cam=full["obs_cam"][m], obs_pt=full["obs_pt"][m], obs_xy=full["obs_xy"][m]))
+    return out
+
+
+def test_append_extends_the_resident_structure(gpu):
+    """SURVEY 8(f) f1 (incremental append): ba_append on a growing problem gives, at every stage, the reduced system
+    and the solution of a FRESH handle on that stage; the driver's pattern (new observations see new points only) is
+    appended in place, anything else is rebuilt inside the handle -- same numbers."""
+    stages = _grow_h4(5)
+    kw = dict(loss="huber", f_scale=1.5, max_iter=60)
+    with _capi.Handle(_capi.Arrays.from_dict(stages[0]), **kw) as h:
+        h.run()
+        for p in stages[1:]:
+            assert len(p["obs_cam"]) > h.arr.struct.n_obs and np.array_equal(p["obs_cam"][:h.arr.struct.n_obs], h.arr.obs_cam)
+            assert h.append(_capi.Arrays.from_dict(p)) is True                 # appended, not rebuilt
+            with _capi.Handle(_capi.Arrays.from_dict(p), **kw) as fresh:
+                h.build(1e-3); fresh.build(1e-3)
+                ra, rb = h.reduced_system(), fresh.reduced_system()
+                for k in ("S", "gred", "U", "gc", "V", "gp"):
+                    assert rel(ra[k], rb[k]) < 1e-11, k
+                h.append(_capi.Arrays.from_dict(p))                            # (same sizes: still the append path, nothing new)
+                fresh.set_values(_capi.Arrays.from_dict(p))
+                s1, s2 = h.run(), fresh.run()
+                assert s1["status"] == s2["status"] and s1["iterations"] == s2["iterations"]
+                assert s1["initial_cost"] == s2["initial_cost"]
+                assert abs(s1["final_cost"] - s2["final_cost"]) <= 1e-9 * s2["final_cost"]
+                np.testing.assert_allclose(h.state()[0], fresh.state()[0], rtol=1e-6, atol=1e-8)
+                np.testing.assert_allclose(h.state()[1], fresh.state()[1], rtol=1e-5, atol=1e-7)
+        # an OLD track grows (someone records the partner image's observation too): rebuilt inside the handle, same numbers
+        p = stages[-1]
+        q = dict(p)
+        k = int(np.flatnonzero(p["obs_cam"] == 2)[0])
+        q["obs_cam"] = np.concatenate([p["obs_cam"], [3]]).astype(np.int32)
+        q["obs_pt"] = np.concatenate([p["obs_pt"], [p["obs_pt"][k]]]).astype(np.int32)
+        q["obs_xy"] = np.concatenate([p["obs_xy"], p["obs_xy"][k:k + 1] + 0.5])
+        assert h.append(_capi.Arrays.from_dict(q)) is False
+        with _capi.Handle(_capi.Arrays.from_dict(q), **kw) as fresh:
+            h.build(1e-3); fresh.build(1e-3)
+            ra, rb = h.reduced_system(), fresh.reduced_system()
+            for k in ("S", "gred", "U", "gc", "V", "gp"):
+                assert rel(ra[k], rb[k]) < 1e-11, k
+        # the gauge of an old camera changes (15th image: the second anchor is released): not a prefix -> rebuilt
+        r = dict(q); r["cam_fixed"] = q["cam_fixed"].copy(); r["cam_fixed"][1] = 0
+        assert h.append(_capi.Arrays.from_dict(r)) is False
+        s = h.run()
+        assert s["iterations"] > 0
+        # a problem that shrank is refused
+        with pytest.raises(_capi.BaError) as ei:
+            h.append(_capi.Arrays.from_dict(stages[0]))
+        assert ei.value.code == _capi.BA_ERR_INVALID
+
+
+def test_append_on_a_dense_track_problem(gpu):
+    """ba_append where the new part is not trivial: a street whose second half (cameras, points with tracks of up to
+    16, observations) arrives later; new points are seen by new AND old cameras (allowed: the POINTS are new)."""
+    full = synthetic.make_street(40, 1800, 8000, seed=7, outlier_frac=0.02)
+    # points sorted by their first camera; the first stage holds the points whose tracks end before camera 20
+    last = np.zeros(len(full["points"]), np.int64); np.maximum.at(last, full["obs_pt"], full["obs_cam"])
+    order = np.argsort(last, kind="stable"); inv = np.argsort(order)
+    pts = full["points"][order]; opt_ = inv[full["obs_pt"]]
+    n1 = int((last[order] < 20).sum())
+    m1 = opt_ < n1
+    first = dict(cam_pose=full["cam_pose"][:20], cam_intr=full["cam_intr"][:20], cam_fixed=full["cam_fixed"][:20], points=pts[:n1],
+                 obs_cam=full["obs_cam"][m1], obs_pt=opt_[m1].astype(np.int32), obs_xy=full["obs_xy"][m1])
+    grown = dict(cam_pose=full["cam_pose"], cam_intr=full["cam_intr"], cam_fixed=full["cam_fixed"], points=pts,
+                 obs_cam=np.concatenate([full["obs_cam"][m1], full["obs_cam"][~m1]]),
+                 obs_pt=np.concatenate([opt_[m1], opt_[~m1]]).astype(np.int32),
+                 obs_xy=np.concatenate([full["obs_xy"][m1], full["obs_xy"][~m1]]))
+    with _capi.Handle(_capi.Arrays.from_dict(first)) as h, _capi.Handle(_capi.Arrays.from_dict(grown)) as fresh:
+        h.run(3)
+        assert h.append(_capi.Arrays.from_dict(grown)) is True
+        h.build(1e-4); fresh.build(1e-4)
+        ra, rb = h.reduced_system(), fresh.reduced_system()
+        for k in ("S", "gred", "U", "gc", "V", "gp"):
+            assert rel(ra[k], rb[k]) < 1e-11, k
+        s1, s2 = h.run(8), fresh.run(8)
+        assert s1["iterations"] == s2["iterations"] and abs(s1["final_cost"] - s2["final_cost"]) <= 1e-8 * s2["final_cost"]
+
+
 def test_heavy_points_and_slotless_cameras(gpu):
     """Tracks longer than a chunk (3 landmarks seen by all 270 cameras: heavy-point kernels) next to windows of up to
     60 cameras (more than a chunk has LDS camera tiles: the slot-less path), 5 % outliers: reduced system against the
