@@ -1,0 +1,262 @@
+// Multi-workgroup dense fp64 Cholesky solve of the reduced camera system: 768 < 6 Nf <= BA_DENSE_BIG_MAX unknowns
+// whose block pattern is (nearly) full -- every camera sees the same landmarks, an object-centric capture: the case
+// SURVEY.md 8(d) calls a genuine dense contraction (n^3 / 3 = 4e11 flop at 10.7 k unknowns).  ba_dense.h covers
+// n <= 768 in ONE workgroup; here the whole chip works on the trailing update.
+//
+// Blocked right-looking factorisation A = L L^T, block size 64, in place in the lower triangle of a row-major
+// M x M matrix (M = n + 1 rounded up to a multiple of 64):
+//   * row n is the right-hand side -g ("augmented" matrix): it goes through the panel solve and the trailing update like
+//     any other row, so when the factorisation is done it holds y = L^-1 (-g) -- the forward substitution costs nothing;
+//     rows behind it are padding with a unit diagonal;
+//   * per block column k, three launches:
+//       k_big_potrf  ONE wave: Cholesky of the 64 x 64 diagonal block in registers (a row per lane) and the explicit
+//                    inverse of its factor (so that the panel solve below is a matrix product);
+//       k_big_trsm   one workgroup per 64 rows below: panel <- panel Linv^T on the fp64 matrix cores;
+//       k_big_syrk   one workgroup per 64 x 64 tile of the trailing lower triangle: tile -= P_I P_J^T, 64 MFMAs
+//                    (v_mfma_f64_16x16x4_f64) per wave, operand tiles staged through LDS;
+//   * backward substitution L^T x = y, one launch per block column from the last to the first: every workgroup forms
+//     x_k = Linv_k^T y_k (64 x 64, redundantly) and takes x_k out of one earlier block of y (a contiguous 64 x 64 block
+//     row of L).
+// The diagonal-block factorisation is a serial chain of one wave (about 50 us per block) during which the chip idles:
+// a third of the solve at 10 k unknowns (see big_solve_launch for the look-ahead that was tried).
+// About 4 n / 64 launches, queued without host synchronisation; a non-positive pivot sets
+// *info (the LM step is then void and repeated with PCG, as for the other direct solvers).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "ba_dense.h"
+
+#define BA_DENSE_BIG_MAX 12288   // unknowns: 2048 free cameras; the matrix takes 1.2 GB
+#define BA_BIG_NB 64
+
+namespace ba {
+
+inline int big_padded(int n) { return ((n + 1 + BA_BIG_NB - 1) / BA_BIG_NB) * BA_BIG_NB; }
+inline size_t big_matrix_doubles(int n) { return (size_t)big_padded(n) * big_padded(n); }
+inline size_t big_linv_doubles(int n) { return (size_t)(big_padded(n) / BA_BIG_NB) * BA_BIG_NB * BA_BIG_NB; }
+
+// S (upper 6x6 blocks) -> lower triangle of the M x M matrix (leading dimension M); A was zeroed before
+__global__ void k_big_assemble(int n_upper, const long long *__restrict__ keys, const double *__restrict__ S, int M,
+                               double *__restrict__ A) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_upper * 36) return;
+    const int k = e / 36, ab = e - k * 36, a = ab / 6, b = ab - a * 6;
+    const int i = (int)(keys[k] >> 32), j = (int)(keys[k] & 0xffffffffLL);   // i <= j: upper block (i, j)
+    const double v = S[e];
+    const size_t r = (size_t)i * 6 + a, c = (size_t)j * 6 + b;
+    if (i == j) {
+        if (a >= b) A[r * M + c] = 0.5 * (v + S[(size_t)k * 36 + b * 6 + a]);   // symmetrised lower half of the diagonal block
+    } else {
+        A[c * M + r] = v;   // lower block (j, i) = upper block transposed
+    }
+}
+
+// right-hand-side row, its (never used) diagonal entry, unit diagonal of the padding
+__global__ void k_big_init(int n, int M, const double *__restrict__ g, double *__restrict__ A) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) A[(size_t)n * M + t] = -g[t];
+    else if (t == n) A[(size_t)n * M + n] = 1e300;   // (larger than any |y|^2: the row's own pivot stays positive)
+    else if (t < M) A[(size_t)t * M + t] = 1.0;
+}
+
+// Cholesky of the 64 x 64 diagonal block at k0 and the inverse of its factor.  ONE wave, no LDS, no barriers: lane r
+// holds row r of the block in registers (statically indexed: the loops are fully unrolled), the pivot row's entries
+// travel through readlane.  (The first version kept the block in LDS with three barriers per column: 87 us per block,
+// a quarter of the whole factorisation at 10 k unknowns.)
+__device__ __forceinline__ double big_readlane(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__global__ __launch_bounds__(64) void k_big_potrf(int k0, int M, double *__restrict__ A, double *__restrict__ Linv,
+                                                  int *__restrict__ info) {
+    constexpr int NB = BA_BIG_NB;
+    const int lane = threadIdx.x;
+    double row[NB];
+    {
+        const double *src = &A[(size_t)(k0 + lane) * M + k0];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) row[c] = src[c];   // (entries right of the diagonal are never used)
+    }
+    int bad = 0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const double d = big_readlane(row[j], j);
+        if (!(d > 0.0) && bad == 0) bad = k0 + j + 1;
+        const double inv = 1.0 / sqrt(d > 0.0 ? d : 1.0);
+        row[j] *= inv;                                   // column j of L (lanes above the diagonal hold junk, unused)
+#pragma unroll
+        for (int c = j + 1; c < NB; ++c) {
+            const double lc = big_readlane(row[j], c);   // L[c][j]
+            row[c] = fma(-row[j], lc, row[c]);           // A[r][c] -= L[r][j] L[c][j]   (used for r >= c)
+        }
+    }
+    {
+        double *dst = &A[(size_t)(k0 + lane) * M + k0];
+#pragma unroll
+        for (int c = 0; c < NB; ++c)
+            if (c <= lane) dst[c] = row[c];
+    }
+    // X = L^-1, lane = column c of X: x_r = (delta_rc - sum_{k < r} L[r][k] x_k) / L[r][r], L[r][k] broadcast from lane r
+    double x[NB];
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+        double sum = (r == lane) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < r; ++k) sum = fma(-big_readlane(row[k], r), x[k], sum);
+        x[r] = sum / big_readlane(row[r], r);
+        if (r < lane) x[r] = 0.0;                        // (upper triangle of the inverse)
+    }
+#pragma unroll
+    for (int r = 0; r < NB; ++r) Linv[r * NB + lane] = x[r];
+    if (lane == 0 && bad != 0) atomicCAS(info, 0, bad);
+}
+
+// panel rows r0 .. r0+63 (r0 = k0 + 64 (1 + blockIdx.x)): P <- P Linv^T.  256 threads = 4 waves of 16 rows.
+__global__ __launch_bounds__(256) void k_big_trsm(int k0, int M, double *__restrict__ A, const double *__restrict__ Linv) {
+    constexpr int NB = BA_BIG_NB, LD = NB + 1;
+    __shared__ double sP[NB * LD];
+    __shared__ double sI[NB * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int r0 = k0 + NB * (1 + blockIdx.x);
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int r = e / NB, c = e - r * NB;
+        sP[r * LD + c] = A[(size_t)(r0 + r) * M + k0 + c];
+        sI[r * LD + c] = Linv[e];
+    }
+    __syncthreads();
+    // out[i][c] = sum_k P[i][k] Linv[c][k]: operand A = P[row l15][k], operand B = Linv[row l15 (= output column)][k]
+    mfma_d4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+    const double *pa = &sP[(wv * 16 + l15) * LD + l4];
+#pragma unroll
+    for (int kc = 0; kc < NB; kc += 4) {
+        const double a = pa[kc];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const double b = sI[(t * 16 + l15) * LD + kc + l4];
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+        }
+    }
+    // accumulator element v of a lane: row l4 + 4 v, column l15 of the 16 x 16 tile
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) A[(size_t)(r0 + wv * 16 + l4 + 4 * v) * M + k0 + t * 16 + l15] = acc[t][v];
+}
+
+// trailing update: tile (I, J), I >= J, of the lower triangle behind block column k:  C -= P_I P_J^T.
+// blockIdx.x enumerates the tile pairs row by row; 256 threads = 4 waves of 16 rows x 64 columns.  The two 64 x 64
+// operand tiles are staged through LDS in two halves of K (coalesced 256-byte row pieces): read straight from L2, one
+// MFMA operand load touches 16 cache lines for 512 useful bytes and the vector cache becomes the limit (the first
+// version ran at 16 % of the MFMA rate).  34 KB of LDS per workgroup: four workgroups per CU.
+__global__ __launch_bounds__(256) void k_big_syrk(int k0, int M, double *__restrict__ A) {
+    constexpr int NB = BA_BIG_NB, KH = 32, LD = KH + 1;
+    __shared__ double sA[NB * LD];
+    __shared__ double sB[NB * LD];
+    // (I, J) from the linear index t = I (I + 1) / 2 + J
+    const int t = blockIdx.x;
+    int I = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((I + 1) * (I + 2) / 2 <= t) ++I;
+    while (I * (I + 1) / 2 > t) --I;
+    const int J = t - I * (I + 1) / 2;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int rI = k0 + NB * (1 + I), rJ = k0 + NB * (1 + J);
+    mfma_d4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+    const int lr = tid >> 2, lc = (tid & 3) * 8;   // loader: row lr, eight consecutive k
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const double *ga = &A[(size_t)(rI + lr) * M + k0 + h * KH + lc], *gb = &A[(size_t)(rJ + lr) * M + k0 + h * KH + lc];
+        double va[8], vb[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { va[k] = ga[k]; vb[k] = gb[k]; }
+        if (h) __syncthreads();   // everybody is done with the first half
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { sA[lr * LD + lc + k] = va[k]; sB[lr * LD + lc + k] = vb[k]; }
+        __syncthreads();
+        const double *pa = &sA[(wv * 16 + l15) * LD + l4];
+#pragma unroll
+        for (int kc = 0; kc < KH; kc += 4) {
+            const double a = pa[kc];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sB[(q * 16 + l15) * LD + kc + l4], acc[q], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        double *cp = &A[(size_t)(rI + wv * 16 + l4 + 4 * v) * M + rJ + l15];
+        double old[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) old[q] = cp[q * 16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cp[q * 16] = old[q] - acc[q][v];
+    }
+}
+
+// backward substitution, block column kb (k0 = 64 kb), launched for kb = last .. 0 with grid kb + 1:
+// every workgroup forms x_k = Linv_k^T y_k; workgroup j < kb takes it out of y_j (y lives in row n of A), workgroup kb
+// stores x_k.  Only indices < n count (the right-hand-side row and the padding carry no unknowns).
+__global__ __launch_bounds__(256) void k_big_back(int kb, int n, int M, double *__restrict__ A, const double *__restrict__ Linv_all,
+                                                  double *__restrict__ x) {
+    constexpr int NB = BA_BIG_NB;
+    __shared__ double sx[NB];
+    __shared__ double sred[4][NB];
+    const int tid = threadIdx.x, k0 = kb * NB;
+    const double *Linv = Linv_all + (size_t)kb * NB * NB;
+    double *y = A + (size_t)n * M;
+    const int rmax = n - k0 < NB ? n - k0 : NB;   // unknowns in this block
+    {
+        // x_k[c] = sum_r Linv[r][c] y[r] (Linv is lower triangular: r >= c); thread (c, part) takes r = part mod 4
+        const int c = tid & 63, part = tid >> 6;
+        double s = 0.0;
+        for (int r = part; r < rmax; r += 4) s += Linv[r * NB + c] * y[k0 + r];
+        sred[part][c] = s;
+        __syncthreads();
+        if (tid < NB) sx[tid] = tid < rmax ? (sred[0][tid] + sred[1][tid]) + (sred[2][tid] + sred[3][tid]) : 0.0;
+        __syncthreads();
+    }
+    const int j = blockIdx.x;
+    if (j == kb) {
+        if (tid < rmax) x[k0 + tid] = sx[tid];
+        return;
+    }
+    // y_j[c] -= sum_r L[k0 + r][j0 + c] x_k[r]
+    const int c = tid & 63, part = tid >> 6, j0 = j * NB;
+    double s = 0.0;
+    for (int r = part * 16; r < part * 16 + 16; ++r)
+        if (r < rmax) s += A[(size_t)(k0 + r) * M + j0 + c] * sx[r];
+    sred[part][c] = s;
+    __syncthreads();
+    if (tid < NB) y[j0 + tid] -= (sred[0][tid] + sred[1][tid]) + (sred[2][tid] + sred[3][tid]);
+}
+
+// x = -S^{-1} g.  A: big_matrix_doubles(n), Linv: big_linv_doubles(n); *info (device) = 0 on success.
+// (Tried: look-ahead over a second stream -- the diagonal factorisation of column k + 1 beside the bulk of column k's
+// update.  The streams did overlap, but the lone factorisation wave needs 320 registers and only became resident when
+// the update's waves had drained from a SIMD: no gain.  CU-masked streams, which would have given it CUs of its own,
+// crash inside hipExtStreamCreateWithCUMask on this ROCm 7.2 / gfx950 stack, tools/cumask_probe.hip.)
+inline hipError_t big_solve_launch(hipStream_t st, int n, int n_upper, const long long *keys, const double *S, const double *g,
+                                   double *x, double *A, double *Linv, int *info) {
+    const int M = big_padded(n), nblk = M / BA_BIG_NB;
+    hipError_t e;
+    if ((e = hipMemsetAsync(A, 0, big_matrix_doubles(n) * sizeof(double), st)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(info, 0, sizeof(int), st)) != hipSuccess) return e;
+    const int ne = n_upper * 36;
+    hipLaunchKernelGGL(k_big_assemble, dim3((ne + 255) / 256), dim3(256), 0, st, n_upper, keys, S, M, A);
+    hipLaunchKernelGGL(k_big_init, dim3((M + 255) / 256), dim3(256), 0, st, n, M, g, A);
+    for (int kb = 0; kb < nblk; ++kb) {
+        const int k0 = kb * BA_BIG_NB, below = nblk - 1 - kb;
+        double *li = Linv + (size_t)kb * BA_BIG_NB * BA_BIG_NB;
+        hipLaunchKernelGGL(k_big_potrf, dim3(1), dim3(64), 0, st, k0, M, A, li, info);
+        if (below > 0) {
+            hipLaunchKernelGGL(k_big_trsm, dim3(below), dim3(256), 0, st, k0, M, A, li);
+            hipLaunchKernelGGL(k_big_syrk, dim3(below * (below + 1) / 2), dim3(256), 0, st, k0, M, A);
+        }
+    }
+    for (int kb = (n - 1) / BA_BIG_NB; kb >= 0; --kb)
+        hipLaunchKernelGGL(k_big_back, dim3(kb + 1), dim3(256), 0, st, kb, n, M, A, Linv, x);
+    return hipGetLastError();
+}
+
+}  // namespace ba

@@ -20,6 +20,7 @@
 #include "../../include/ba_hip.h"
 #include "ba_banded.h"
 #include "ba_dense.h"
+#include "ba_dense_big.h"
 #include "ba_kernels.h"
 #include "ba_heavy.h"
 
@@ -238,7 +239,8 @@ struct BaHandle {
     DevBuf<unsigned long long> stamps;  // diagnostic (ba_debug_stamps)
     DevBuf<double> px, pr, pz, pp, pq, pqv;  // PCG: x, r, z, p (double-buffered: pp / pq), q = S p
     DevBuf<PcgScalars> pcg_sc;
-    DevBuf<double> dense_a;          // dense reduced system (small camera counts only)
+    DevBuf<double> dense_a;          // dense reduced system (one-workgroup solver, or the blocked multi-workgroup one)
+    DevBuf<double> dense_linv;       // blocked solver: inverse factors of the diagonal blocks
     DevBuf<double> band_l, band_y, band_g, band_mid;  // block-banded factor, work vectors, separator system
     DevBuf<long long> upper_keys;
     DevBuf<int> dense_info;
@@ -466,6 +468,22 @@ int do_dense(BaHandle *h, bool *launched) {
     return BA_OK;  // (the pivot flag in dense_info is read together with the step's outcome, see do_step)
 }
 
+// blocked multi-workgroup dense Cholesky (ba_dense_big.h), launched only
+int do_dense_big(BaHandle *h, bool *launched) {
+    const int n = h->sym.n_free * 6;
+    *launched = false;
+    if (n == 0) return BA_OK;
+    *launched = true;
+    if (h->dense_a.n != big_matrix_doubles(n)) {
+        HIPCHK(h->dense_a.alloc(big_matrix_doubles(n)));
+        HIPCHK(h->dense_linv.alloc(big_linv_doubles(n)));
+        if (h->dense_info.n == 0) HIPCHK(h->dense_info.alloc(1));
+    }
+    HIPCHK(big_solve_launch(h->stream, n, h->n_upper, h->upper_keys.p, h->S, h->gred, h->px.p, h->dense_a.p, h->dense_linv.p,
+                            h->dense_info.p));
+    return BA_OK;  // (pivot flag: see do_step)
+}
+
 // block-banded Cholesky solve of S x = -g_red, launched only
 int do_banded(BaHandle *h, bool *launched) {
     hipStream_t st = h->stream;
@@ -531,11 +549,16 @@ int do_step(BaHandle *h) {
     const int n_red = s.n_free * 6;
     bool direct = false;
     const int ls = h->opt.linear_solver;
-    const bool can_dense = n_red <= BA_DENSE_MAX, can_band = s.band <= BA_BAND_MAX;
+    const bool can_dense = n_red <= BA_DENSE_MAX, can_band = s.band <= BA_BAND_MAX, can_big = n_red <= BA_DENSE_BIG_MAX;
+    // "a genuine dense contraction": at least a quarter of the 6x6 blocks of S are there (every camera shares landmarks
+    // with most others); a sparse S of that size is cheaper through PCG
+    const bool dense_pattern = (double)h->n_full >= 0.25 * (double)s.n_free * (double)s.n_free;
     if ((ls == BA_SOLVER_AUTO || ls == BA_SOLVER_DENSE_CHOLESKY) && can_dense) {
         if ((e = do_dense(h, &direct))) return e;
-    } else if ((ls == BA_SOLVER_AUTO || ls == BA_SOLVER_BANDED_CHOLESKY || ls == BA_SOLVER_DENSE_CHOLESKY) && can_band) {
+    } else if ((ls == BA_SOLVER_AUTO || ls == BA_SOLVER_BANDED_CHOLESKY) && can_band) {
         if ((e = do_banded(h, &direct))) return e;
+    } else if (can_big && (ls == BA_SOLVER_DENSE_CHOLESKY || (ls == BA_SOLVER_AUTO && dense_pattern))) {
+        if ((e = do_dense_big(h, &direct))) return e;
     }
     if (direct) {
         // The direct solvers leave a pivot flag on the device.  The rest of the step is queued behind them without
@@ -645,7 +668,7 @@ int alloc_work(BaHandle *h) {
     HIPCHK(h->pcg_sc.alloc(1));
     HIPCHK(h->state.alloc(1));
     // solver work space is sized on first use: drop what belonged to another structure
-    h->dense_a.release();
+    h->dense_a.release(); h->dense_linv.release();
     h->band_l.release(); h->band_y.release(); h->band_g.release(); h->band_mid.release();
     h->dbg_v.release(); h->dbg_gp.release();
     h->pattern_uploaded = false;

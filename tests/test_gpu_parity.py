@@ -274,6 +274,39 @@ def test_dense_cholesky_at_its_size_limit(gpu):
     np.testing.assert_allclose(out["dense_cholesky"][1].cam_pose, out["banded_cholesky"][1].cam_pose, rtol=1e-6, atol=1e-7)
 
 
+def test_blocked_dense_cholesky_matches_banded(gpu):
+    """The multi-workgroup blocked dense Cholesky (768 < unknowns <= 12288, ba_dense_big.h) against the banded
+    factorisation on street chains: 200 cameras (1188 unknowns: ragged last block) and 150 cameras (888), same LM path."""
+    for nc, n_pts, n_obs, seed in ((200, 5000, 22000, 51), (150, 3500, 15000, 52)):
+        p = synthetic.make_street(nc, n_pts, n_obs, seed=seed, outlier_frac=0.01)
+        out = {}
+        for solver in ("banded_cholesky", "dense_cholesky"):
+            arr = _capi.Arrays.from_dict(p)
+            out[solver] = (_capi.solve(arr, loss="huber", f_scale=1.0, max_iter=15, linear_solver=solver), arr)
+        sb, sd = out["banded_cholesky"][0], out["dense_cholesky"][0]
+        assert sd["pcg_iterations"] == 0 and sb["pcg_iterations"] == 0          # neither fell back
+        assert sb["iterations"] == sd["iterations"] and sb["accepted"] == sd["accepted"]
+        assert sd["final_cost"] < 0.05 * sd["initial_cost"]
+        assert abs(sb["final_cost"] - sd["final_cost"]) <= 1e-9 * sd["final_cost"]
+        np.testing.assert_allclose(out["dense_cholesky"][1].cam_pose, out["banded_cholesky"][1].cam_pose, rtol=1e-6, atol=1e-7)
+
+
+def test_blocked_dense_cholesky_at_ladybug_size(gpu):
+    """10 326 unknowns (the Ladybug-1723 shape, BASELINE.json configs[2]): three LM steps with the blocked dense solver
+    forced, against the banded solver -- the size SURVEY.md 8(d) calls MFMA-worthy."""
+    p = synthetic.make_config("ladybug1723")
+    out = {}
+    for solver in ("banded_cholesky", "dense_cholesky"):
+        with _capi.Handle(_capi.Arrays.from_dict(p), loss="huber", f_scale=1.0, linear_solver=solver) as h:
+            s = h.run(3)
+            out[solver] = (s, h.state()[0])
+    sb, sd = out["banded_cholesky"][0], out["dense_cholesky"][0]
+    assert sd["pcg_iterations"] == 0 and sb["accepted"] == sd["accepted"] and sd["accepted"] >= 1
+    assert abs(sb["final_cost"] - sd["final_cost"]) <= 1e-8 * sd["final_cost"]
+    np.testing.assert_allclose(out["dense_cholesky"][1], out["banded_cholesky"][1], rtol=1e-5, atol=1e-6)
+    print("3 LM steps at 10326 unknowns: banded %.1f ms, blocked dense %.1f ms" % (sb["t_solve_ms"], sd["t_solve_ms"]))
+
+
 def test_set_values_reuses_the_structure(gpu):
     """SURVEY 8(f) f1 (device-resident reuse): ba_set_values on a handle that has already solved problem A gives,
     for new values B on the same structure, the reduced system and the solution of a fresh handle on B; a problem
