@@ -379,22 +379,30 @@ int do_build(BaHandle *h, bool timed) {
     }
     if (timed) HIPCHK(hipEventRecord(h->ev1, st));
     if (h->n_heavy > 0) hipLaunchKernelGGL(k_build_heavy, dim3(h->n_heavy), dim3(256), 0, st, build_args(h), heavy_args(h));
-    hipLaunchKernelGGL(k_chunk_totals, dim3(1), dim3(1024), 0, st, h->n_chunks + h->n_heavy, h->ck_cost.p, h->ck_gmax.p, h->sums, h->gm2.p);
-    if (h->coll) {
+    if (!h->coll) {
+        // single GPU: nothing has to happen between the kernels behind the build -- two launches instead of four
+        if (nf > 0)
+            hipLaunchKernelGGL(k_apply_finalize, dim3((h->n_upper + nf + 127) / 128), dim3(128), 0, st, nf, h->n_upper, h->upper_keys.p,
+                               h->free_cam.p, h->aux[h->cur].p, h->S, h->U, h->gc, h->gred, h->diag_slot.p, h->Minv.p,
+                               h->cam_gmax.p, h->state.p);
+        hipLaunchKernelGGL(k_totals_state, dim3(1), dim3(1024), 0, st, h->n_chunks + h->n_heavy, h->ck_cost.p, h->ck_gmax.p, h->sums,
+                           h->gm2.p, h->state.p, nf, h->cam_gmax.p);
+    } else {
+        hipLaunchKernelGGL(k_chunk_totals, dim3(1), dim3(1024), 0, st, h->n_chunks + h->n_heavy, h->ck_cost.p, h->ck_gmax.p, h->sums, h->gm2.p);
         // ONE collective per build: the maximum over ranks of the point-gradient norm rides in the sum buffer,
         // each rank's value in its own slot of the tail (zero elsewhere), and is maximised locally afterwards
         hipLaunchKernelGGL(k_copy_scalar, dim3(1), dim3(1), 0, st, h->gm2.p, h->red.p + nred + h->rank);
         int e = call_coll(h, h->red.p, (int64_t)nred + h->world, BA_REDUCE_SUM);
         if (e) return e;
         hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(256), 0, st, h->world, h->red.p + nred, h->gm2.p);
+        if (nf > 0) {  // (after the all-reduce: the transform is linear, and every rank holds the same cameras)
+            hipLaunchKernelGGL(k_apply_jl, dim3((h->n_upper + nf + 127) / 128), dim3(128), 0, st, nf, h->n_upper, h->upper_keys.p,
+                               h->free_cam.p, h->aux[h->cur].p, h->S, h->U, h->gc, h->gred);
+            hipLaunchKernelGGL(k_finalize, dim3((nf + 63) / 64), dim3(64), 0, st, nf, h->U, h->gc, h->gred, h->S, h->diag_slot.p,
+                               h->Minv.p, h->cam_gmax.p, h->state.p);
+        }
+        hipLaunchKernelGGL(k_state_after_build, dim3(1), dim3(256), 0, st, h->state.p, h->sums, h->gm2.p, nf, h->cam_gmax.p);
     }
-    if (nf > 0)  // (after the all-reduce: the transform is linear, and every rank holds the same cameras)
-        hipLaunchKernelGGL(k_apply_jl, dim3((h->n_upper + nf + 127) / 128), dim3(128), 0, st, nf, h->n_upper, h->upper_keys.p,
-                           h->free_cam.p, h->aux[h->cur].p, h->S, h->U, h->gc, h->gred);
-    if (nf > 0)
-        hipLaunchKernelGGL(k_finalize, dim3((nf + 63) / 64), dim3(64), 0, st, nf, h->U, h->gc, h->gred, h->S, h->diag_slot.p,
-                           h->Minv.p, h->cam_gmax.p, h->state.p);
-    hipLaunchKernelGGL(k_state_after_build, dim3(1), dim3(256), 0, st, h->state.p, h->sums, h->gm2.p, nf, h->cam_gmax.p);
     HIPCHK(hipGetLastError());
     h->built = true;
     return BA_OK;

@@ -516,78 +516,80 @@ __device__ __forceinline__ bool spd6_inverse(const double *__restrict__ Ain, dou
 // The build kernels linearise in the local rotation tangent (load_aux_local).  This brings the accumulated reduced
 // system to the rvec parameters the solver steps in, once per build pass: with D = diag(Jl, I) per camera,
 // U = D^T U' D, g = D^T g', S_ij = D_i^T S'_ij D_j.  One thread per upper block, then one per free camera.
+__device__ __forceinline__ void apply_jl_block(int t, const long long *__restrict__ keys, const int *__restrict__ free_cam,
+                                               const double *__restrict__ aux, double *__restrict__ S) {
+    const int i = (int)(keys[t] >> 32), j = (int)(keys[t] & 0xffffffff);
+    const double *Ji = aux + (size_t)free_cam[i] * BA_CAM_AUX + 9, *Jj = aux + (size_t)free_cam[j] * BA_CAM_AUX + 9;
+    double *blk = &S[(size_t)t * 36];
+    double B[36], ji[9], jj[9];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) B[k] = blk[k];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { ji[k] = Ji[k]; jj[k] = Jj[k]; }
+    double T3[18];  // Ji^T * (top three rows)
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) T3[r * 6 + c] = ji[r] * B[c] + ji[3 + r] * B[6 + c] + ji[6 + r] * B[12 + c];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) B[k] = T3[k];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {  // (left three columns) * Jj
+        const double b0 = B[r * 6], b1 = B[r * 6 + 1], b2 = B[r * 6 + 2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) B[r * 6 + c] = b0 * jj[c] + b1 * jj[3 + c] + b2 * jj[6 + c];
+    }
+#pragma unroll
+    for (int k = 0; k < 36; ++k) blk[k] = B[k];
+}
+__device__ __forceinline__ void apply_jl_camera(int f, const int *__restrict__ free_cam, const double *__restrict__ aux,
+                                                double *__restrict__ U, double *__restrict__ gc, double *__restrict__ gred) {
+    const double *J = aux + (size_t)free_cam[f] * BA_CAM_AUX + 9;
+    double jl[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) jl[k] = J[k];
+    double *u = &U[(size_t)f * 21];
+    double B[36];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = r; c < 6; ++c) B[r * 6 + c] = B[c * 6 + r] = u[ut6(r, c)];
+    double T3[18];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) T3[r * 6 + c] = jl[r] * B[c] + jl[3 + r] * B[6 + c] + jl[6 + r] * B[12 + c];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) B[k] = T3[k];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const double b0 = B[r * 6], b1 = B[r * 6 + 1], b2 = B[r * 6 + 2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) B[r * 6 + c] = b0 * jl[c] + b1 * jl[3 + c] + b2 * jl[6 + c];
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = r; c < 6; ++c) u[ut6(r, c)] = (r < 3 && c < 3 && r != c) ? 0.5 * (B[r * 6 + c] + B[c * 6 + r]) : B[r * 6 + c];
+    double *g1 = &gc[(size_t)f * 6], *g2 = &gred[(size_t)f * 6];
+    const double a0 = g1[0], a1 = g1[1], a2 = g1[2], b0 = g2[0], b1 = g2[1], b2 = g2[2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        g1[r] = jl[r] * a0 + jl[3 + r] * a1 + jl[6 + r] * a2;
+        g2[r] = jl[r] * b0 + jl[3 + r] * b1 + jl[6 + r] * b2;
+    }
+}
 __global__ void k_apply_jl(int nf, int n_upper, const long long *__restrict__ keys, const int *__restrict__ free_cam,
                            const double *__restrict__ aux, double *__restrict__ S, double *__restrict__ U,
                            double *__restrict__ gc, double *__restrict__ gred) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n_upper) {
-        const int i = (int)(keys[t] >> 32), j = (int)(keys[t] & 0xffffffff);
-        const double *Ji = aux + (size_t)free_cam[i] * BA_CAM_AUX + 9, *Jj = aux + (size_t)free_cam[j] * BA_CAM_AUX + 9;
-        double *blk = &S[(size_t)t * 36];
-        double B[36], ji[9], jj[9];
-#pragma unroll
-        for (int k = 0; k < 36; ++k) B[k] = blk[k];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) { ji[k] = Ji[k]; jj[k] = Jj[k]; }
-        double T3[18];  // Ji^T * (top three rows)
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 6; ++c) T3[r * 6 + c] = ji[r] * B[c] + ji[3 + r] * B[6 + c] + ji[6 + r] * B[12 + c];
-#pragma unroll
-        for (int k = 0; k < 18; ++k) B[k] = T3[k];
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {  // (left three columns) * Jj
-            const double b0 = B[r * 6], b1 = B[r * 6 + 1], b2 = B[r * 6 + 2];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) B[r * 6 + c] = b0 * jj[c] + b1 * jj[3 + c] + b2 * jj[6 + c];
-        }
-#pragma unroll
-        for (int k = 0; k < 36; ++k) blk[k] = B[k];
-    } else if (t < n_upper + nf) {
-        const int f = t - n_upper;
-        const double *J = aux + (size_t)free_cam[f] * BA_CAM_AUX + 9;
-        double jl[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) jl[k] = J[k];
-        double *u = &U[(size_t)f * 21];
-        double B[36];
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int c = r; c < 6; ++c) B[r * 6 + c] = B[c * 6 + r] = u[ut6(r, c)];
-        double T3[18];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 6; ++c) T3[r * 6 + c] = jl[r] * B[c] + jl[3 + r] * B[6 + c] + jl[6 + r] * B[12 + c];
-#pragma unroll
-        for (int k = 0; k < 18; ++k) B[k] = T3[k];
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            const double b0 = B[r * 6], b1 = B[r * 6 + 1], b2 = B[r * 6 + 2];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) B[r * 6 + c] = b0 * jl[c] + b1 * jl[3 + c] + b2 * jl[6 + c];
-        }
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int c = r; c < 6; ++c) u[ut6(r, c)] = (r < 3 && c < 3 && r != c) ? 0.5 * (B[r * 6 + c] + B[c * 6 + r]) : B[r * 6 + c];
-        double *g1 = &gc[(size_t)f * 6], *g2 = &gred[(size_t)f * 6];
-        const double a0 = g1[0], a1 = g1[1], a2 = g1[2], b0 = g2[0], b1 = g2[1], b2 = g2[2];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            g1[r] = jl[r] * a0 + jl[3 + r] * a1 + jl[6 + r] * a2;
-            g2[r] = jl[r] * b0 + jl[3 + r] * b1 + jl[6 + r] * b2;
-        }
-    }
+    if (t < n_upper) apply_jl_block(t, keys, free_cam, aux, S);
+    else if (t < n_upper + nf) apply_jl_camera(t - n_upper, free_cam, aux, U, gc, gred);
 }
 
-__global__ void k_finalize(int nf, const double *__restrict__ U, const double *__restrict__ gc, double *__restrict__ gred,
+__device__ __forceinline__ void finalize_camera(int f, const double *__restrict__ U, const double *__restrict__ gc, double *__restrict__ gred,
                            double *__restrict__ S, const int *__restrict__ diag_slot, double *__restrict__ Minv,
                            double *__restrict__ cam_gmax, const LmState *__restrict__ st) {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= nf) return;
     const double lam = st->lambda;
     double *blk = &S[(size_t)diag_slot[f] * 36];
     const double *u = &U[(size_t)f * 21];
@@ -629,6 +631,29 @@ __global__ void k_finalize(int nf, const double *__restrict__ U, const double *_
         gm = fmax(gm, fabs(g));
     }
     cam_gmax[f] = gm;
+}
+
+__global__ void k_finalize(int nf, const double *__restrict__ U, const double *__restrict__ gc, double *__restrict__ gred,
+                           double *__restrict__ S, const int *__restrict__ diag_slot, double *__restrict__ Minv,
+                           double *__restrict__ cam_gmax, const LmState *__restrict__ st) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < nf) finalize_camera(f, U, gc, gred, S, diag_slot, Minv, cam_gmax, st);
+}
+// k_apply_jl and k_finalize in one launch (single-GPU build pass: nothing has to happen between them).  A camera's
+// thread transforms its own diagonal block (the block threads leave the diagonal keys alone) and finalises it.
+__global__ void k_apply_finalize(int nf, int n_upper, const long long *__restrict__ keys, const int *__restrict__ free_cam,
+                                 const double *__restrict__ aux, double *__restrict__ S, double *__restrict__ U,
+                                 double *__restrict__ gc, double *__restrict__ gred, const int *__restrict__ diag_slot,
+                                 double *__restrict__ Minv, double *__restrict__ cam_gmax, const LmState *__restrict__ st) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_upper) {
+        if ((int)(keys[t] >> 32) != (int)(keys[t] & 0xffffffff)) apply_jl_block(t, keys, free_cam, aux, S);
+    } else if (t < n_upper + nf) {
+        const int f = t - n_upper;
+        apply_jl_block(diag_slot[f], keys, free_cam, aux, S);
+        apply_jl_camera(f, free_cam, aux, U, gc, gred);
+        finalize_camera(f, U, gc, gred, S, diag_slot, Minv, cam_gmax, st);
+    }
 }
 
 // ------------------------------------------------------------------ PCG on S x = -g_red
@@ -926,6 +951,54 @@ __global__ void k_copy_scalar(const double *src, double *dst) { *dst = *src; }
 // *out = NaN when *bad is set (an index was out of range), else unchanged
 __global__ void k_nan_if(const int *bad, double *out) {
     if (*bad) *out = __longlong_as_double(0x7ff8000000000000LL);
+}
+
+// (single-GPU build pass) k_chunk_totals and k_state_after_build in one launch, after k_apply_finalize: same fixed-order
+// sums as k_chunk_totals, then F and ||g||_inf into the state
+__global__ __launch_bounds__(1024) void k_totals_state(int n, const double *__restrict__ ck_cost, const double *__restrict__ ck_gmax,
+                                                       double *__restrict__ sum_out, double *__restrict__ gm, LmState *st, int nf,
+                                                       const double *__restrict__ cam_gmax) {
+    __shared__ double rs[16], rm[16], rc[16];
+    double s = 0.0, m = 0.0, mc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 4096) {
+        double c[4], g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = i + u * 1024;
+            const int j = idx < n ? idx : i;
+            c[u] = ck_cost[j];
+            g[u] = ck_gmax[j];
+            if (idx >= n) c[u] = g[u] = 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            s += c[u];
+            m = fmax(m, g[u]);
+        }
+    }
+    for (int i = threadIdx.x; i < nf; i += 1024) mc = fmax(mc, cam_gmax[i]);
+    s = wave_sum(s);
+    m = wave_max(m);
+    mc = wave_max(mc);
+    if ((threadIdx.x & 63) == 0) {
+        rs[threadIdx.x >> 6] = s;
+        rm[threadIdx.x >> 6] = m;
+        rc[threadIdx.x >> 6] = mc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ts = 0.0, tm = 0.0, tc = 0.0;
+        for (int w = 0; w < 16; ++w) {
+            ts += rs[w];
+            tm = fmax(tm, rm[w]);
+            tc = fmax(tc, rc[w]);
+        }
+        *sum_out = ts;
+        gm[0] = tm;
+        gm[1] = tc;
+        st->F = ts;
+        st->gmax = fmax(tm, tc);
+    }
 }
 
 // after k_build, ONE 1024-thread block: *sum_out = sum of the chunk costs (fixed order -> bitwise reproducible),
