@@ -76,12 +76,29 @@ struct DevBuf {
         p = nullptr;
         n = cap = 0;
     }
+    // (contents are NOT kept; an allocation that is already large enough is re-used -- ba_append / ba_set_values size their
+    // work buffers again and again, and a hipFree + hipMalloc pair costs tens of microseconds)
     hipError_t alloc(size_t count) {
+        if (p && count <= cap && count > 0) {
+            n = count;
+            return hipSuccess;
+        }
         release();
         n = count;
         if (count == 0) count = 1;
         cap = count;
         return hipMalloc((void **)&p, count * sizeof(T));
+    }
+    // the same with head room for a structure that is expected to grow (ba_append)
+    hipError_t alloc_grow(size_t count) {
+        if (p && count <= cap && count > 0) {
+            n = count;
+            return hipSuccess;
+        }
+        release();
+        n = count;
+        cap = count + count / 4 + 16;
+        return hipMalloc((void **)&p, cap * sizeof(T));
     }
     // ba_append: new elements behind the first `keep` ones, which stay where they are in HBM.  The allocation grows
     // geometrically (device-to-device copy of the kept part) so that a sequence of appends re-allocates rarely.
@@ -292,7 +309,7 @@ int upload_pattern(BaHandle *h) {
         HIPCHK(h->upper_keys.upload(keys, st));
     }
     const size_t nS = (size_t)h->n_upper * 36, nU = (size_t)nf * 21, ng = (size_t)nf * 6;
-    HIPCHK(h->red.alloc(nS + nU + 2 * ng + 4 + BA_MAX_WORLD));  // tail: one slot per rank (see do_build)
+    HIPCHK(h->red.alloc_grow(nS + nU + 2 * ng + 4 + BA_MAX_WORLD));  // tail: one slot per rank (see do_build)
     h->S = h->red.p;
     h->U = h->S + nS;
     h->gc = h->U + nU;
@@ -655,24 +672,24 @@ int check_options(BaOptions &o) {
 int alloc_work(BaHandle *h) {
     const Symbolic &s = h->sym;
     const int nf = s.n_free;
-    for (int b = 0; b < 2; ++b) HIPCHK(h->aux[b].alloc((size_t)s.n_cams * BA_CAM_AUX));
-    HIPCHK(h->Minv.alloc((size_t)nf * 36));
-    HIPCHK(h->cam_gmax.alloc((size_t)nf));
+    for (int b = 0; b < 2; ++b) HIPCHK(h->aux[b].alloc_grow((size_t)s.n_cams * BA_CAM_AUX));
+    HIPCHK(h->Minv.alloc_grow((size_t)nf * 36));
+    HIPCHK(h->cam_gmax.alloc_grow((size_t)nf));
     HIPCHK(h->gm2.alloc(2));
-    HIPCHK(h->pt_linv.alloc((size_t)s.n_pts_obs * 6));
-    HIPCHK(h->pt_u.alloc((size_t)s.n_pts_obs * 3));
-    HIPCHK(h->ck_cost.alloc((size_t)(h->n_chunks + h->n_heavy)));
-    HIPCHK(h->ck_gmax.alloc((size_t)(h->n_chunks + h->n_heavy)));
-    HIPCHK(h->ck_part.alloc((size_t)(h->n_chunks + h->n_heavy) * 4));
-    HIPCHK(h->cam_part.alloc((size_t)s.n_cams * 2));
+    HIPCHK(h->pt_linv.alloc_grow((size_t)s.n_pts_obs * 6));
+    HIPCHK(h->pt_u.alloc_grow((size_t)s.n_pts_obs * 3));
+    HIPCHK(h->ck_cost.alloc_grow((size_t)(h->n_chunks + h->n_heavy)));
+    HIPCHK(h->ck_gmax.alloc_grow((size_t)(h->n_chunks + h->n_heavy)));
+    HIPCHK(h->ck_part.alloc_grow((size_t)(h->n_chunks + h->n_heavy) * 4));
+    HIPCHK(h->cam_part.alloc_grow((size_t)s.n_cams * 2));
     HIPCHK(h->step_sums.alloc(4));
     HIPCHK(h->cam_sums.alloc(2));
-    HIPCHK(h->px.alloc((size_t)nf * 6));
-    HIPCHK(h->pr.alloc((size_t)nf * 6));
-    HIPCHK(h->pz.alloc((size_t)nf * 6));
-    HIPCHK(h->pp.alloc((size_t)nf * 6));
-    HIPCHK(h->pq.alloc((size_t)nf * 6));
-    HIPCHK(h->pqv.alloc((size_t)nf * 6));
+    HIPCHK(h->px.alloc_grow((size_t)nf * 6));
+    HIPCHK(h->pr.alloc_grow((size_t)nf * 6));
+    HIPCHK(h->pz.alloc_grow((size_t)nf * 6));
+    HIPCHK(h->pp.alloc_grow((size_t)nf * 6));
+    HIPCHK(h->pq.alloc_grow((size_t)nf * 6));
+    HIPCHK(h->pqv.alloc_grow((size_t)nf * 6));
     HIPCHK(h->pcg_sc.alloc(1));
     HIPCHK(h->state.alloc(1));
     // solver work space is sized on first use: drop what belonged to another structure
