@@ -157,6 +157,118 @@ def _valid_track_entries(cam_data, n_points):
             yield kp_idx, point_idx
 
 
+def _track_arrays(cam_data, n_points):
+    """(keypoint indices, point indices) of one image as arrays, under the reference's rules (:260-264)."""
+    ref_array, kp = cam_data[3], cam_data[5]
+    if isinstance(ref_array, list) and set(map(type, ref_array)) <= {int}:
+        ref = np.asarray(ref_array, dtype=np.int64)
+        ok = (ref != -1) & (ref >= 0) & (ref < n_points)
+        ok[len(kp):] = False
+        kidx = np.flatnonzero(ok)
+        return kidx, ref[kidx]
+    pairs = list(_valid_track_entries(cam_data, n_points))        # anything unusual: the generic rules
+    if not pairs:
+        return np.zeros(0, np.int64), np.zeros(0, np.int64)
+    a = np.array(pairs, dtype=np.int64)
+    return a[:, 0], a[:, 1]
+
+
+def _image_data_to_arrays(image_data, all_points_3D, visited_ids, keypoints=None):
+    """The driver's containers -> (Arrays without gauge, cam_ids, colours (Np, 3) or None), with NumPy instead of one
+    Python object per observation.  Same camera order, observation order and validity rules as
+    ``prepare_cameras_from_image_data`` + ``prepare_observations_from_image_data`` + ``_to_arrays`` (the tests compare
+    them array by array).  ``keypoints(img_id, kp) -> (k, 2) float64`` lets a caller cache the pixel coordinates."""
+    pts6 = np.asarray(all_points_3D, dtype=np.float64)
+    if pts6.ndim != 2 or pts6.shape[1] < 3:
+        pts6 = np.array([[p[0], p[1], p[2]] for p in all_points_3D], dtype=np.float64).reshape(-1, 3)
+    points = np.ascontiguousarray(pts6[:, :3])
+    colours = pts6[:, 3:6] if pts6.shape[1] >= 6 else None
+    n_points = len(points)
+    usable = [i for i in visited_ids if i in image_data and len(image_data[i]) >= 6]
+    cam_ids = list(dict.fromkeys(usable))
+    index_of = {cid: i for i, cid in enumerate(cam_ids)}
+    n_c = len(cam_ids)
+    cam_pose, cam_intr = np.empty((n_c, 6)), np.empty((n_c, 4))
+    for i, cid in enumerate(cam_ids):
+        R, t, K = image_data[cid][0], image_data[cid][1], image_data[cid][2]
+        cam_pose[i, :3] = matrix_to_rvec(np.asarray(R, dtype=np.float64))
+        cam_pose[i, 3:] = np.asarray(t, dtype=np.float64).reshape(3)
+        K = np.asarray(K, dtype=np.float64)
+        cam_intr[i] = (K[0, 0], K[1, 1], K[0, 2], K[1, 2])
+    oc, op, oxy = [], [], []
+    for img_id in usable:                         # per occurrence, like the reference's loop (:253)
+        cam_data = image_data[img_id]
+        kidx, pidx = _track_arrays(cam_data, n_points)
+        if len(kidx):
+            kp = cam_data[5]
+            xy = keypoints(img_id, kp) if keypoints is not None else None
+            oc.append(np.full(len(kidx), index_of[img_id], dtype=np.int32))
+            op.append(pidx.astype(np.int32))
+            oxy.append(xy[kidx] if xy is not None else np.array([kp[k].pt for k in kidx], dtype=np.float64).reshape(-1, 2))
+    obs_cam = np.concatenate(oc) if oc else np.zeros(0, np.int32)
+    obs_pt = np.concatenate(op) if op else np.zeros(0, np.int32)
+    obs_xy = np.concatenate(oxy) if oxy else np.zeros((0, 2))
+    arr = _capi.Arrays(cam_pose, cam_intr, np.zeros(n_c, np.uint8), points, obs_cam, obs_pt, obs_xy)
+    return arr, cam_ids, colours
+
+
+def _ba_from_image_data(image_data, all_points_3D, visited_ids, loss_f_scale, max_nfev, verbose, min_obs=None,
+                        keypoints=None, run=None):
+    """What ``prepare_cameras`` + ``prepare_observations`` + ``global_bundle_adjustment`` + ``update_image_data`` do for
+    ``inter_ba`` / ``final_ba`` (BundleAdjustment.py:316-350, 361-385), on arrays: same guards, prints, gauge, success rule
+    and in-place update of ``image_data``; no list of observation dicts in between (82 k dicts and arrays per call at the
+    Temple size).  ``min_obs``: inter_ba's extra guard (:325).  ``run(arr, **opts) -> summary`` replaces the one-shot
+    ``_capi.solve`` (BASession keeps its handle there).  Returns (points, success, cam_ids, fixed_ids, attempted) -- attempted = got past inter_ba's own guard."""
+    global last_summary
+    arr, cam_ids, colours = _image_data_to_arrays(image_data, all_points_3D, visited_ids, keypoints)
+    n_c, n_p, n_o = len(cam_ids), len(arr.points), len(arr.obs_cam)
+    if min_obs is not None and (n_c < 3 or n_p < 10 or n_o < min_obs):
+        if verbose:
+            print("[BA] Insufficient data for BA")
+        return all_points_3D, False, cam_ids, set(), False
+    if n_c < 3 or n_p < 10:
+        print(f"[BA] Insufficient data: {n_c} cameras, {n_p} points")
+        return all_points_3D, False, cam_ids, set(), True
+    print(f"[BA] Starting BA with {n_c} cameras, {n_p} points, {n_o} observations")
+    first_id, second_id, anchor_second = _anchor_ids(cam_ids, visited_ids)
+    fixed_ids = {first_id, second_id} if anchor_second else {first_id}
+    if verbose:
+        print(f"[BA] Anchoring cameras: {[first_id, second_id] if anchor_second else [first_id]}")
+    for i, cid in enumerate(cam_ids):
+        arr.cam_fixed[i] = cid in fixed_ids
+    try:
+        if n_o and (arr.obs_pt.min() < 0 or arr.obs_pt.max() >= n_p):
+            raise KeyError(int(arr.obs_pt.max()))
+        opts = dict(loss="huber", f_scale=float(loss_f_scale), max_iter=int(max_nfev), ftol=1e-8, xtol=1e-8, gtol=1e-8,
+                    verbose=2 if verbose else 0)
+        summary = run(arr, **opts) if run is not None else _capi.solve(arr, **opts)
+        last_summary = summary
+        success, converged = _reference_success(summary)
+        if not success:
+            if verbose:
+                print(f"[BA] Bundle adjustment failed: status {summary['status']} after {summary['iterations']} steps")
+            return all_points_3D, False, cam_ids, fixed_ids, True
+        if verbose:
+            print(f"[BA] Bundle adjustment {'converged' if converged else 'improved significantly'}! Cost: {summary['final_cost']:.6f}")
+        R_new = rvec_to_matrix(arr.cam_pose[:, :3])
+        for i, cid in enumerate(cam_ids):         # in-place update of the tuples (:298-306); anchors keep their pose
+            entry = list(image_data[cid])
+            if cid in fixed_ids:
+                entry[0] = np.asarray(entry[0]).astype(np.float64)
+                entry[1] = np.asarray(entry[1]).astype(np.float64).reshape(3, 1)
+            else:
+                entry[0], entry[1] = R_new[i].copy(), arr.cam_pose[i, 3:].reshape(3, 1).copy()
+            image_data[cid] = tuple(entry)
+        if colours is not None:
+            new_points = np.concatenate([arr.points, colours], axis=1).tolist()
+        else:
+            new_points = [[x, y, z] + list(p[3:6]) for (x, y, z), p in zip(arr.points.tolist(), all_points_3D)]
+        return new_points, True, cam_ids, fixed_ids, True
+    except Exception as e:                        # as the reference: any failure -> (inputs, False) (:238-240)
+        print(f"[BA] Bundle adjustment error: {e}")
+        return all_points_3D, False, cam_ids, fixed_ids, True
+
+
 def prepare_observations_from_image_data(image_data, visited_ids, all_points_3D):
     """image_data tuples -> observation dicts, camera-major in ``visited_ids`` order, keypoint
     order inside a camera (BundleAdjustment.py:243-272).  This defines the residual order."""
@@ -218,24 +330,15 @@ def inter_ba(image_data, all_points_3D, visited_ids,
         print(f"RUNNING BUNDLE ADJUSTMENT - {len(visited_ids)} images processed")
         print(f"{'=' * 50}")
 
-    cameras = prepare_cameras_from_image_data(image_data, visited_ids)
-    observations = prepare_observations_from_image_data(image_data, visited_ids, all_points_3D)
-
-    if len(cameras) < 3 or len(all_points_3D) < 10 or len(observations) < 20:
-        if verbose:
-            print("[BA] Insufficient data for BA")
-        return all_points_3D, image_data, False
-
-    optimized_cameras, optimized_points, success = global_bundle_adjustment(
-        cameras, all_points_3D, observations, visited_ids,
-        robust_loss='huber', loss_f_scale=1.5, max_nfev=150, verbose=verbose)
-
+    # (the reference goes through prepare_cameras / prepare_observations / global_bundle_adjustment /
+    # update_image_data_from_ba_results here; _ba_from_image_data does the same on arrays)
+    optimized_points, success, cam_ids, _, attempted = _ba_from_image_data(image_data, all_points_3D, visited_ids, 1.5, 150,
+                                                                            verbose, min_obs=20)
     if success:
-        image_data = update_image_data_from_ba_results(image_data, optimized_cameras)
         if verbose:
-            print(f"[BA] Successfully optimized {len(optimized_cameras)} cameras and {len(optimized_points)} points")
+            print(f"[BA] Successfully optimized {len(cam_ids)} cameras and {len(optimized_points)} points")
         return optimized_points, image_data, True
-    if verbose:
+    if verbose and attempted:
         print("[BA] Bundle adjustment failed")
     return all_points_3D, image_data, False
 
@@ -248,15 +351,8 @@ def final_ba(image_data, all_points_3D, visited_ids, verbose=True):
         print("RUNNING FINAL BUNDLE ADJUSTMENT")
         print(f"{'=' * 60}")
 
-    cameras = prepare_cameras_from_image_data(image_data, visited_ids)
-    observations = prepare_observations_from_image_data(image_data, visited_ids, all_points_3D)
-
-    optimized_cameras, optimized_points, success = global_bundle_adjustment(
-        cameras, all_points_3D, observations, visited_ids,
-        robust_loss='huber', loss_f_scale=1.0, max_nfev=300, verbose=verbose)
-
+    optimized_points, success = _ba_from_image_data(image_data, all_points_3D, visited_ids, 1.0, 300, verbose)[:2]
     if success:
-        image_data = update_image_data_from_ba_results(image_data, optimized_cameras)
         if verbose:
             print("[BA] Final BA completed successfully!")
         return optimized_points, image_data, True

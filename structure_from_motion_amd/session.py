@@ -98,102 +98,27 @@ class BASession:
         else:
             self._kp_xy.pop(img_id, None)
 
-    def _track_entries(self, img_id, cam_data, n_points):
-        """(keypoint indices, point indices) of one image under the reference's rules (:260-264)."""
-        ref_array, kp = cam_data[3], cam_data[5]
-        if isinstance(ref_array, list) and set(map(type, ref_array)) <= {int}:
-            ref = np.asarray(ref_array, dtype=np.int64)
-            ok = (ref != -1) & (ref >= 0) & (ref < n_points)
-            ok[len(kp):] = False
-            kidx = np.flatnonzero(ok)
-            return kidx, ref[kidx]
-        pairs = list(_ba._valid_track_entries(cam_data, n_points))    # anything unusual: the generic rules
-        if not pairs:
-            return np.zeros(0, np.int64), np.zeros(0, np.int64)
-        a = np.array(pairs, dtype=np.int64)
-        return a[:, 0], a[:, 1]
-
     def marshal(self, image_data, all_points_3D, visited_ids):
         """-> (Arrays without gauge, cam_ids, colours (Np, 3) or None).  Same camera / observation order as
-        ``prepare_cameras_from_image_data`` + ``prepare_observations_from_image_data`` + ``_to_arrays``."""
-        pts6 = np.asarray(all_points_3D, dtype=np.float64)
-        if pts6.ndim != 2 or pts6.shape[1] < 3:
-            pts6 = np.array([[p[0], p[1], p[2]] for p in all_points_3D], dtype=np.float64).reshape(-1, 3)
-        points = np.ascontiguousarray(pts6[:, :3])
-        colours = pts6[:, 3:6] if pts6.shape[1] >= 6 else None
-        n_points = len(points)
-        usable = [i for i in visited_ids if i in image_data and len(image_data[i]) >= 6]
-        cam_ids = list(dict.fromkeys(usable))
-        index_of = {cid: i for i, cid in enumerate(cam_ids)}
-        n_c = len(cam_ids)
-        cam_pose, cam_intr = np.empty((n_c, 6)), np.empty((n_c, 4))
-        for i, cid in enumerate(cam_ids):
-            R, t, K = image_data[cid][0], image_data[cid][1], image_data[cid][2]
-            cam_pose[i, :3] = matrix_to_rvec(np.asarray(R, dtype=np.float64))
-            cam_pose[i, 3:] = np.asarray(t, dtype=np.float64).reshape(3)
-            K = np.asarray(K, dtype=np.float64)
-            cam_intr[i] = (K[0, 0], K[1, 1], K[0, 2], K[1, 2])
-        oc, op, oxy = [], [], []
-        for img_id in usable:                         # per occurrence, like the reference's loop (:253)
-            cam_data = image_data[img_id]
-            kidx, pidx = self._track_entries(img_id, cam_data, n_points)
-            if len(kidx):
-                oc.append(np.full(len(kidx), index_of[img_id], dtype=np.int32))
-                op.append(pidx.astype(np.int32))
-                oxy.append(self._keypoints(img_id, cam_data[5])[kidx])
-        obs_cam = np.concatenate(oc) if oc else np.zeros(0, np.int32)
-        obs_pt = np.concatenate(op) if op else np.zeros(0, np.int32)
-        obs_xy = np.concatenate(oxy) if oxy else np.zeros((0, 2))
-        arr = _capi.Arrays(cam_pose, cam_intr, np.zeros(n_c, np.uint8), points, obs_cam, obs_pt, obs_xy)
-        return arr, cam_ids, colours
+        ``prepare_cameras_from_image_data`` + ``prepare_observations_from_image_data`` + ``_to_arrays``; the keypoint
+        coordinates of an image are converted once per session."""
+        return _ba._image_data_to_arrays(image_data, all_points_3D, visited_ids, keypoints=self._keypoints)
 
     # ------------------------------------------------------------------ solves
     def _solve(self, image_data, all_points_3D, visited_ids, f_scale, max_nfev, verbose, min_obs):
-        arr, cam_ids, colours = self.marshal(image_data, all_points_3D, visited_ids)
-        n_c, n_p, n_o = len(cam_ids), len(arr.points), len(arr.obs_cam)
-        if n_c < 3 or n_p < 10 or n_o < min_obs:
-            print("[BA] Insufficient data for BA" if min_obs else f"[BA] Insufficient data: {n_c} cameras, {n_p} points")
-            return all_points_3D, image_data, False
-        print(f"[BA] Starting BA with {n_c} cameras, {n_p} points, {n_o} observations")
-        first_id, second_id, anchor_second = _ba._anchor_ids(cam_ids, visited_ids)
-        fixed_ids = {first_id, second_id} if anchor_second else {first_id}
-        for i, cid in enumerate(cam_ids):
-            arr.cam_fixed[i] = cid in fixed_ids
         self._resident = None
-        try:
-            if n_o and (arr.obs_pt.min() < 0 or arr.obs_pt.max() >= n_p):
-                raise KeyError(int(arr.obs_pt.max()))
-            s = self._run(arr, loss="huber", f_scale=float(f_scale), max_iter=int(max_nfev),
-                          ftol=1e-8, xtol=1e-8, gtol=1e-8, verbose=2 if verbose else 0)
-            self.last_summary = _ba.last_summary = s
-            if not _ba._reference_success(s)[0]:
-                if verbose:
-                    print(f"[BA] Bundle adjustment failed: status {s['status']} after {s['iterations']} steps")
-                return all_points_3D, image_data, False
-            R_new = rvec_to_matrix(arr.cam_pose[:, :3])
-            for i, cid in enumerate(cam_ids):         # in-place update of the tuples (:298-306); anchors keep theirs
-                entry = list(image_data[cid])
-                if cid in fixed_ids:
-                    entry[0] = np.asarray(entry[0]).astype(np.float64)
-                    entry[1] = np.asarray(entry[1]).astype(np.float64).reshape(3, 1)
-                else:
-                    entry[0], entry[1] = R_new[i].copy(), arr.cam_pose[i, 3:].reshape(3, 1).copy()
-                image_data[cid] = tuple(entry)
-            if colours is not None:
-                new_points = np.concatenate([arr.points, colours], axis=1).tolist()
-            else:
-                new_points = [[x, y, z] + list(p[3:6]) for (x, y, z), p in zip(arr.points.tolist(), all_points_3D)]
-            if self._handle is not None:
-                # the handle's device state IS what was just written back: remember the very objects, so that a
-                # following compute_ba_reprojection_errors can tell that nothing was replaced in between
-                self._resident = dict(cam_ids=list(cam_ids), points=new_points, n_points=len(new_points),
-                                      R={c: image_data[c][0] for c in cam_ids}, t={c: image_data[c][1] for c in cam_ids},
-                                      ref={c: (image_data[c][3], len(image_data[c][3])) for c in cam_ids},
-                                      kp={c: (image_data[c][5], len(image_data[c][5])) for c in cam_ids})
-            return new_points, image_data, True
-        except Exception as e:                        # as the reference: any failure -> (inputs, False) (:238-240)
-            print(f"[BA] Bundle adjustment error: {e}")
-            return all_points_3D, image_data, False
+        new_points, ok, cam_ids, _fixed, _att = _ba._ba_from_image_data(image_data, all_points_3D, visited_ids, f_scale, max_nfev,
+                                                                       verbose, min_obs=min_obs, keypoints=self._keypoints,
+                                                                       run=self._run)
+        self.last_summary = _ba.last_summary
+        if ok and self._handle is not None:
+            # the handle's device state IS what was just written back: remember the very objects, so that a
+            # following compute_ba_reprojection_errors can tell that nothing was replaced in between
+            self._resident = dict(cam_ids=list(cam_ids), points=new_points, n_points=len(new_points),
+                                  R={c: image_data[c][0] for c in cam_ids}, t={c: image_data[c][1] for c in cam_ids},
+                                  ref={c: (image_data[c][3], len(image_data[c][3])) for c in cam_ids},
+                                  kp={c: (image_data[c][5], len(image_data[c][5])) for c in cam_ids})
+        return new_points, image_data, ok
 
     def inter_ba(self, image_data, all_points_3D, visited_ids, ba_interval=10, verbose=True):
         """As ``inter_ba`` (``BundleAdjustment.py:309-350``): huber, f_scale 1.5, max_nfev 150."""
@@ -203,7 +128,7 @@ class BASession:
 
     def final_ba(self, image_data, all_points_3D, visited_ids, verbose=True):
         """As ``final_ba`` (``BundleAdjustment.py:353-385``): huber, f_scale 1.0, max_nfev 300."""
-        return self._solve(image_data, all_points_3D, visited_ids, 1.0, 300, verbose, min_obs=0)
+        return self._solve(image_data, all_points_3D, visited_ids, 1.0, 300, verbose, min_obs=None)
 
     def compute_ba_reprojection_errors(self, image_data, all_points_3D, visited_ids):
         """As ``compute_ba_reprojection_errors`` (``BundleAdjustment.py:388-423``), which the reference's driver calls
