@@ -7,11 +7,27 @@
 #include <cstdio>
 #include <cstdlib>
 #include <numeric>
+#include <thread>
 #include <unordered_map>
 
 #include "../../include/ba_hip.h"
 
 namespace ba {
+
+namespace {
+// fn(lo, hi) over [0, n) on up to 8 host threads (large n only).  Used where the result does not depend on the split.
+template <typename F>
+void parallel_for(int64_t n, F fn) {
+    constexpr int T = 8;
+    if (n < 200000) {
+        fn((int64_t)0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) th.emplace_back([&, t] { fn(n * t / T, n * (t + 1) / T); });
+    for (auto &x : th) x.join();
+}
+}  // namespace
 
 int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *cam_fixed,
                       const int32_t *obs_cam, const int32_t *obs_pt, Symbolic &s, const char **err) {
@@ -29,22 +45,33 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
             s.free_cam.push_back(c);
         }
     // --- observations per point, validity -------------------------------------------------
+    // (one pass on host threads: count, smallest and largest camera per point -- integer atomics, so the result does not
+    // depend on the interleaving)
     std::vector<int32_t> cnt(n_points + 1, 0);
-    for (int64_t k = 0; k < n_obs; ++k) {
-        if (obs_cam[k] < 0 || obs_cam[k] >= n_cams || obs_pt[k] < 0 || obs_pt[k] >= n_points) {
+    std::vector<int32_t> cmin(n_points, INT32_MAX), cmax(n_points, -1);
+    {
+        int bad = 0;
+        parallel_for(n_obs, [&](int64_t lo, int64_t hi) {
+            for (int64_t k = lo; k < hi; ++k) {
+                const int32_t c = obs_cam[k], p = obs_pt[k];
+                if (c < 0 || c >= n_cams || p < 0 || p >= n_points) {
+                    __atomic_store_n(&bad, 1, __ATOMIC_RELAXED);
+                    continue;
+                }
+                __atomic_fetch_add(&cnt[p], 1, __ATOMIC_RELAXED);
+                int32_t cur = __atomic_load_n(&cmin[p], __ATOMIC_RELAXED);
+                while (c < cur && !__atomic_compare_exchange_n(&cmin[p], &cur, c, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+                cur = __atomic_load_n(&cmax[p], __ATOMIC_RELAXED);
+                while (c > cur && !__atomic_compare_exchange_n(&cmax[p], &cur, c, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+            }
+        });
+        if (bad) {
             *err = "observation index out of range";
             return BA_ERR_INVALID;
         }
-        cnt[obs_pt[k]]++;
     }
     tick("count");
     // --- point order: observed points sorted by (min camera, max camera), unobserved last ----
-    std::vector<int32_t> cmin(n_points, INT32_MAX), cmax(n_points, -1);
-    for (int64_t k = 0; k < n_obs; ++k) {
-        int p = obs_pt[k], c = obs_cam[k];
-        cmin[p] = std::min(cmin[p], c);
-        cmax[p] = std::max(cmax[p], c);
-    }
     // (two stable counting passes, by max camera then by min camera: O(Np + Nc), keeps index order among ties)
     s.pt_order.resize(n_points);
     {
@@ -81,20 +108,28 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
     for (int i = 0; i < n_points; ++i) pstart[i + 1] = pstart[i] + cnt[s.pt_order[i]];
     s.obs_order.resize(n_obs);
     {
+        // (scatter by point on host threads -- the order inside a point's run is settled by the sort that follows, whose
+        // key (camera, caller's index) is total)
         std::vector<int64_t> fill(pstart.begin(), pstart.end() - 1);
-        for (int64_t k = 0; k < n_obs; ++k) s.obs_order[fill[pt_inv[obs_pt[k]]]++] = k;
-        for (int i = 0; i < s.n_pts_obs; ++i)
-            std::sort(s.obs_order.begin() + pstart[i], s.obs_order.begin() + pstart[i + 1],
-                      [&](int64_t a, int64_t b) { return obs_cam[a] != obs_cam[b] ? obs_cam[a] < obs_cam[b] : a < b; });
+        parallel_for(n_obs, [&](int64_t lo, int64_t hi) {
+            for (int64_t k = lo; k < hi; ++k) s.obs_order[__atomic_fetch_add(&fill[pt_inv[obs_pt[k]]], (int64_t)1, __ATOMIC_RELAXED)] = k;
+        });
+        parallel_for(s.n_pts_obs, [&](int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; ++i)
+                std::sort(s.obs_order.begin() + pstart[i], s.obs_order.begin() + pstart[i + 1],
+                          [&](int64_t a, int64_t b) { return obs_cam[a] != obs_cam[b] ? obs_cam[a] < obs_cam[b] : a < b; });
+        });
     }
     tick("obs order");
     s.o_cam.resize(n_obs);
     s.o_pt.resize(n_obs);
     s.o_lcam.resize(n_obs);
-    for (int64_t k = 0; k < n_obs; ++k) {
-        s.o_cam[k] = obs_cam[s.obs_order[k]];
-        s.o_pt[k] = pt_inv[obs_pt[s.obs_order[k]]];
-    }
+    parallel_for(n_obs, [&](int64_t lo, int64_t hi) {
+        for (int64_t k = lo; k < hi; ++k) {
+            s.o_cam[k] = obs_cam[s.obs_order[k]];
+            s.o_pt[k] = pt_inv[obs_pt[s.obs_order[k]]];
+        }
+    });
     double track_sum = 0;
     for (int i = 0; i < s.n_pts_obs; ++i) {
         int L = (int)(pstart[i + 1] - pstart[i]);
@@ -103,173 +138,239 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
     }
     tick("obs gather");
     // --- greedy chunking -----------------------------------------------------------------
-    std::vector<int32_t> cam_stamp(std::max(s.n_free, 1), -1), cam_slot(std::max(s.n_free, 1), 0);
-    // local pair ids of the open chunk: a (slot, slot) table for cameras with an LDS slot, a hash map for the rest
-    std::unordered_map<int64_t, int32_t> pair_map;
-    std::vector<int32_t> pair_lut((size_t)CHUNK_CAMS * CHUNK_CAMS, -1), lut_touched;
-    std::vector<int32_t> pair_cnt;  // entries per local pair of the open chunk
-    std::vector<uint32_t> sorted;   // scratch of close_chunk
-    std::vector<int32_t> pair_off;
-    int cur_groups = 0, cur_pairs = 0;
-    auto find_pair = [&](int fa, int fc, int chunk_now) -> int32_t {
-        if (cam_stamp[fa] != chunk_now || cam_stamp[fc] != chunk_now) return -1;
-        const int sa = cam_slot[fa], sc = cam_slot[fc];
-        if (sa >= 0 && sc >= 0) return pair_lut[(size_t)sa * CHUNK_CAMS + sc];
-        auto it = pair_map.find(((int64_t)fa << 32) | (uint32_t)fc);
-        return it == pair_map.end() ? -1 : it->second;
+    // The point range is cut into up to CHUNK_THREADS parts (balanced by observations) that are chunked independently on
+    // host threads and concatenated: a chunk never spans a seam, nothing else differs from one sequential sweep.  The
+    // number of parts depends on the problem size only, not on the machine, so the chunking -- and with it the order of
+    // every floating-point sum of the engine -- is the same everywhere.
+    struct Part {
+        std::vector<int32_t> ck_obs, ck_pt, ck_cam, ck_cam_list, ck_pair, ck_pgrp;
+        std::vector<int64_t> ck_pe, keys;
+        std::vector<uint32_t> pair_entries;
+        int64_t n_pair_real = 0, n_direct_pairs = 0, n_direct_cam_obs = 0;
+        int max_chunk_cams = 0, max_chunk_pairs = 0;
     };
-    std::vector<int64_t> ck_pair_key;  // parallel to ck_pair_slot
+    auto chunk_range = [&](const int p0, const int p1, Part &P) {
+        std::vector<int32_t> cam_stamp(std::max(s.n_free, 1), -1), cam_slot(std::max(s.n_free, 1), 0);
+        // local pair ids of the open chunk: a (slot, slot) table for cameras with an LDS slot, a hash map for the rest
+        std::unordered_map<int64_t, int32_t> pair_map;
+        std::vector<int32_t> pair_lut((size_t)CHUNK_CAMS * CHUNK_CAMS, -1), lut_touched;
+        std::vector<int32_t> pair_cnt;  // entries per local pair of the open chunk
+        std::vector<uint32_t> sorted;   // scratch of close_chunk
+        std::vector<int32_t> pair_off;
+        int cur_groups = 0, cur_pairs = 0;
+        auto find_pair = [&](int fa, int fc, int chunk_now) -> int32_t {
+            if (cam_stamp[fa] != chunk_now || cam_stamp[fc] != chunk_now) return -1;
+            const int sa = cam_slot[fa], sc = cam_slot[fc];
+            if (sa >= 0 && sc >= 0) return pair_lut[(size_t)sa * CHUNK_CAMS + sc];
+            auto it = pair_map.find(((int64_t)fa << 32) | (uint32_t)fc);
+            return it == pair_map.end() ? -1 : it->second;
+        };
+        std::vector<int64_t> &ck_pair_key = P.keys;  // parallel to ck_pair_slot
+        P.ck_obs.push_back((int32_t)pstart[p0]);
+        P.ck_pt.push_back(p0);
+        P.ck_cam.push_back(0);
+        P.ck_pair.push_back(0);
+        P.ck_pe.push_back(0);
+        int chunk = 0, cur_obs = 0, cur_pts = 0, cur_cams = 0;
+        int64_t obs_base = pstart[p0];
+        {
+            double est = 0;  // pair entries: sum of L (L + 1) / 2, plus the padding of the groups
+            for (int i = p0; i < p1; ++i) {
+                const double L = (double)(pstart[i + 1] - pstart[i]);
+                est += 0.5 * L * (L + 1);
+            }
+            P.pair_entries.reserve((size_t)(est * 1.25) + 4096);
+        }
+        auto close_chunk = [&](int next_pt, int64_t next_obs) {
+            P.ck_obs.push_back((int32_t)next_obs);
+            P.ck_pt.push_back(next_pt);
+            P.ck_cam.push_back((int32_t)P.ck_cam_list.size());
+            P.ck_pair.push_back((int32_t)ck_pair_key.size());
+            // Entries of a chunk, sorted by local pair, are cut into GROUPS of PAIR_RUN entry words of ONE camera pair
+            // (null-padded).  Lane pair g of the build kernel reduces group g to one 6x6 partial block in registers; the
+            // partial blocks of a pair (groups ck_pgrp[l] .. ck_pgrp[l+1]) are summed when the chunk is flushed, so the
+            // Schur phase needs no LDS atomics and no LDS tile per pair.  Groups beyond the first CHUNK_OBS / 2 of a
+            // chunk (second "round": long tracks, many small pairs) go to HBM with atomics straight from registers.
+            {
+                const size_t b0 = (size_t)P.ck_pe.back(), ne = P.pair_entries.size() - b0;
+                // counting sort by local pair (stable: entries of a pair stay in point order)
+                pair_off.assign(cur_pairs + 1, 0);
+                for (int l = 0; l < cur_pairs; ++l) pair_off[l + 1] = pair_off[l] + pair_cnt[l];
+                sorted.resize(ne);
+                for (size_t k = 0; k < ne; ++k) {
+                    const uint32_t ent = P.pair_entries[b0 + k];
+                    sorted[pair_off[ent >> 16]++] = ent;
+                }
+                P.n_pair_real += (int64_t)ne;
+                P.pair_entries.resize(b0);
+                int32_t n_groups = 0;
+                size_t i = 0;
+                for (int l = 0; l < cur_pairs; ++l) {
+                    const size_t j = i + pair_cnt[l];
+                    P.ck_pgrp.push_back(n_groups);
+                    // The pair's entries (in point order) are DEALT over the lanes of its groups -- lane 2 g + h of the build
+                    // kernel takes words 4 h .. 4 h + 3 of group g -- so that at every step neighbouring lanes read the T rows
+                    // of neighbouring points: rows a track length apart fall into different LDS banks, where a contiguous cut
+                    // (eight consecutive points per group) put the lanes of one pair 8 tracks apart = the same banks.
+                    const size_t cnt = pair_cnt[l], G = (cnt + PAIR_RUN - 1) / PAIR_RUN, slots = 2 * G;
+                    const size_t w0 = P.pair_entries.size();
+                    P.pair_entries.resize(w0 + G * PAIR_RUN, PAIR_NULL);
+                    for (size_t k = 0; k < cnt; ++k) {
+                        const size_t slot = k % slots, step = k / slots;  // step < PAIR_RUN / 2
+                        P.pair_entries[w0 + (slot >> 1) * PAIR_RUN + (slot & 1) * (PAIR_RUN / 2) + step] = sorted[i + k];
+                    }
+                    n_groups += (int32_t)G;
+                    i = j;
+                }
+                P.ck_pgrp.push_back(n_groups);
+                const size_t per_round = CHUNK_OBS / 2;
+                const size_t rounds = ((size_t)n_groups + per_round - 1) / per_round;
+                P.pair_entries.resize(b0 + rounds * per_round * PAIR_RUN, PAIR_NULL);
+                if (rounds > 1) P.n_direct_pairs += n_groups - (int32_t)per_round;
+            }
+            P.ck_pe.push_back((int64_t)P.pair_entries.size());
+            P.max_chunk_cams = std::max(P.max_chunk_cams, cur_cams);
+            P.max_chunk_pairs = std::max(P.max_chunk_pairs, cur_pairs);
+            pair_map.clear();
+            for (int32_t t : lut_touched) pair_lut[t] = -1;
+            lut_touched.clear();
+            pair_cnt.clear();
+            cur_groups = 0;
+            cur_pairs = 0;
+            ++chunk;
+            cur_obs = cur_pts = cur_cams = 0;
+            obs_base = next_obs;
+        };
+        std::vector<int32_t> fidx;
+        for (int i = p0; i < p1; ++i) {
+            const int64_t b = pstart[i], e = pstart[i + 1];
+            const int L = (int)(e - b);
+            fidx.resize(L);
+            for (int a = 0; a < L; ++a) fidx[a] = s.cam_free[s.o_cam[b + a]];
+            bool cut = cur_obs + L > CHUNK_OBS || cur_pts + 1 > CHUNK_PTS;
+            if (!cut && cur_obs >= CHUNK_OBS / 4) {
+                // soft cut: would this point overflow the LDS tiles?
+                int newc = 0, newp = 0;
+                for (int a = 0; a < L; ++a) {
+                    if (fidx[a] < 0) continue;
+                    bool seen = cam_stamp[fidx[a]] == chunk;
+                    for (int a2 = 0; a2 < a && !seen; ++a2) seen = fidx[a2] == fidx[a];
+                    if (!seen) ++newc;
+                    for (int c = a; c < L; ++c) {
+                        if (fidx[c] < 0) continue;
+                        const int32_t lp = find_pair(fidx[a], fidx[c], chunk);  // (duplicates inside the point over-count: harmless)
+                        if (lp < 0 || pair_cnt[lp] % PAIR_RUN == 0) ++newp;  // opens a new group
+                    }
+                }
+                if (cur_cams + newc > CHUNK_CAMS || cur_groups + newp > CHUNK_OBS / 2) cut = true;
+            }
+            if (cut && cur_pts > 0) close_chunk(i, b);
+            for (int a = 0; a < L; ++a) {
+                int f = fidx[a];
+                int16_t slot = -2;
+                if (f >= 0) {
+                    if (cam_stamp[f] != chunk) {
+                        cam_stamp[f] = chunk;
+                        if (cur_cams < CHUNK_CAMS) {
+                            cam_slot[f] = cur_cams++;
+                            P.ck_cam_list.push_back(f);
+                        } else {
+                            cam_slot[f] = -1;
+                        }
+                    }
+                    slot = (int16_t)cam_slot[f];
+                    if (slot < 0) {
+                        slot = -1;
+                        P.n_direct_cam_obs++;
+                    }
+                }
+                s.o_lcam[b + a] = slot;
+            }
+            for (int a = 0; a < L; ++a) {
+                if (fidx[a] < 0) continue;
+                for (int c = a; c < L; ++c) {
+                    if (fidx[c] < 0) continue;
+                    int32_t lp = find_pair(fidx[a], fidx[c], chunk);
+                    if (lp < 0) {
+                        lp = cur_pairs++;
+                        const int64_t key = ((int64_t)fidx[a] << 32) | (uint32_t)fidx[c];
+                        const int sa = cam_slot[fidx[a]], sc = cam_slot[fidx[c]];
+                        if (sa >= 0 && sc >= 0) {
+                            pair_lut[(size_t)sa * CHUNK_CAMS + sc] = lp;
+                            lut_touched.push_back(sa * CHUNK_CAMS + sc);
+                        } else {
+                            pair_map.emplace(key, lp);
+                        }
+                        ck_pair_key.push_back(key);
+                    }
+                    const uint32_t oi = (uint32_t)(b + a - obs_base), oj = (uint32_t)(b + c - obs_base);
+                    if ((size_t)lp >= pair_cnt.size()) pair_cnt.resize(lp + 1, 0);
+                    P.pair_entries.push_back(oi | (oj << 8) | ((uint32_t)lp << 16));
+                    if (pair_cnt[lp]++ % PAIR_RUN == 0) ++cur_groups;
+                    if (c != a && fidx[c] == fidx[a]) {  // same camera observing the point twice
+                        P.pair_entries.push_back(oj | (oi << 8) | ((uint32_t)lp << 16));
+                        if (pair_cnt[lp]++ % PAIR_RUN == 0) ++cur_groups;
+                    }
+                }
+            }
+            cur_obs += L;
+            cur_pts += 1;
+        }
+        if (cur_pts > 0) close_chunk(p1, pstart[p1]);
+    };
+    constexpr int CHUNK_THREADS = 8;
+    const int n_parts = s.n_pts_chunked >= 40000 ? CHUNK_THREADS : 1;
+    std::vector<Part> parts(n_parts);
+    {
+        std::vector<int> cut(n_parts + 1, 0);
+        cut[n_parts] = s.n_pts_chunked;
+        const int64_t total = pstart[s.n_pts_chunked];
+        for (int t = 1; t < n_parts; ++t)
+            cut[t] = (int)(std::lower_bound(pstart.begin(), pstart.begin() + s.n_pts_chunked + 1, total * t / n_parts) - pstart.begin());
+        for (int t = 1; t <= n_parts; ++t) cut[t] = std::max(cut[t], cut[t - 1]);
+        if (n_parts == 1) {
+            chunk_range(cut[0], cut[1], parts[0]);
+        } else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < n_parts; ++t) th.emplace_back([&, t] { chunk_range(cut[t], cut[t + 1], parts[t]); });
+            for (auto &x : th) x.join();
+        }
+    }
+    tick("chunking (parts)");
+    std::vector<int64_t> ck_pair_key;
     s.ck_obs.push_back(0);
     s.ck_pt.push_back(0);
     s.ck_cam.push_back(0);
     s.ck_pair.push_back(0);
     s.ck_pe.push_back(0);
-    int chunk = 0, cur_obs = 0, cur_pts = 0, cur_cams = 0;
-    int64_t obs_base = 0;
     {
-        double est = 0;  // pair entries: sum of L (L + 1) / 2, plus the padding of the groups
-        for (int i = 0; i < s.n_pts_chunked; ++i) {
-            const double L = (double)(pstart[i + 1] - pstart[i]);
-            est += 0.5 * L * (L + 1);
-        }
-        s.pair_entries.reserve((size_t)(est * 1.25) + 4096);
+        size_t n_pe = 0, n_keys = 0, n_cl = 0, n_pg = 0, n_ck = 0;
+        for (const Part &P : parts) { n_pe += P.pair_entries.size(); n_keys += P.keys.size(); n_cl += P.ck_cam_list.size(); n_pg += P.ck_pgrp.size(); n_ck += P.ck_obs.size(); }
+        s.pair_entries.reserve(n_pe + (size_t)(CHUNK_OBS / 2) * PAIR_RUN);
+        ck_pair_key.reserve(n_keys); s.ck_cam_list.reserve(n_cl); s.ck_pgrp.reserve(n_pg);
+        s.ck_obs.reserve(n_ck); s.ck_pt.reserve(n_ck); s.ck_cam.reserve(n_ck); s.ck_pair.reserve(n_ck); s.ck_pe.reserve(n_ck);
     }
-    auto close_chunk = [&](int next_pt, int64_t next_obs) {
-        s.ck_obs.push_back((int32_t)next_obs);
-        s.ck_pt.push_back(next_pt);
-        s.ck_cam.push_back((int32_t)s.ck_cam_list.size());
-        s.ck_pair.push_back((int32_t)ck_pair_key.size());
-        // Entries of a chunk, sorted by local pair, are cut into GROUPS of PAIR_RUN entry words of ONE camera pair
-        // (null-padded).  Lane pair g of the build kernel reduces group g to one 6x6 partial block in registers; the
-        // partial blocks of a pair (groups ck_pgrp[l] .. ck_pgrp[l+1]) are summed when the chunk is flushed, so the
-        // Schur phase needs no LDS atomics and no LDS tile per pair.  Groups beyond the first CHUNK_OBS / 2 of a
-        // chunk (second "round": long tracks, many small pairs) go to HBM with atomics straight from registers.
-        {
-            const size_t b0 = (size_t)s.ck_pe.back(), ne = s.pair_entries.size() - b0;
-            // counting sort by local pair (stable: entries of a pair stay in point order)
-            pair_off.assign(cur_pairs + 1, 0);
-            for (int l = 0; l < cur_pairs; ++l) pair_off[l + 1] = pair_off[l] + pair_cnt[l];
-            sorted.resize(ne);
-            for (size_t k = 0; k < ne; ++k) {
-                const uint32_t ent = s.pair_entries[b0 + k];
-                sorted[pair_off[ent >> 16]++] = ent;
-            }
-            s.n_pair_real += (int64_t)ne;
-            s.pair_entries.resize(b0);
-            int32_t n_groups = 0;
-            size_t i = 0;
-            for (int l = 0; l < cur_pairs; ++l) {
-                const size_t j = i + pair_cnt[l];
-                s.ck_pgrp.push_back(n_groups);
-                // The pair's entries (in point order) are DEALT over the lanes of its groups -- lane 2 g + h of the build
-                // kernel takes words 4 h .. 4 h + 3 of group g -- so that at every step neighbouring lanes read the T rows
-                // of neighbouring points: rows a track length apart fall into different LDS banks, where a contiguous cut
-                // (eight consecutive points per group) put the lanes of one pair 8 tracks apart = the same banks.
-                const size_t cnt = pair_cnt[l], G = (cnt + PAIR_RUN - 1) / PAIR_RUN, slots = 2 * G;
-                const size_t w0 = s.pair_entries.size();
-                s.pair_entries.resize(w0 + G * PAIR_RUN, PAIR_NULL);
-                for (size_t k = 0; k < cnt; ++k) {
-                    const size_t slot = k % slots, step = k / slots;  // step < PAIR_RUN / 2
-                    s.pair_entries[w0 + (slot >> 1) * PAIR_RUN + (slot & 1) * (PAIR_RUN / 2) + step] = sorted[i + k];
-                }
-                n_groups += (int32_t)G;
-                i = j;
-            }
-            s.ck_pgrp.push_back(n_groups);
-            const size_t per_round = CHUNK_OBS / 2;
-            const size_t rounds = ((size_t)n_groups + per_round - 1) / per_round;
-            s.pair_entries.resize(b0 + rounds * per_round * PAIR_RUN, PAIR_NULL);
-            if (rounds > 1) s.n_direct_pairs += n_groups - (int32_t)per_round;
+    for (Part &P : parts) {
+        const int32_t cl0 = (int32_t)s.ck_cam_list.size(), k0 = (int32_t)ck_pair_key.size();
+        const int64_t pe0 = (int64_t)s.pair_entries.size();
+        for (size_t c = 1; c < P.ck_obs.size(); ++c) {
+            s.ck_obs.push_back(P.ck_obs[c]);
+            s.ck_pt.push_back(P.ck_pt[c]);
+            s.ck_cam.push_back(P.ck_cam[c] + cl0);
+            s.ck_pair.push_back(P.ck_pair[c] + k0);
+            s.ck_pe.push_back(P.ck_pe[c] + pe0);
         }
-        s.ck_pe.push_back((int64_t)s.pair_entries.size());
-        s.max_chunk_cams = std::max(s.max_chunk_cams, cur_cams);
-        s.max_chunk_pairs = std::max(s.max_chunk_pairs, cur_pairs);
-        pair_map.clear();
-        for (int32_t t : lut_touched) pair_lut[t] = -1;
-        lut_touched.clear();
-        pair_cnt.clear();
-        cur_groups = 0;
-        cur_pairs = 0;
-        ++chunk;
-        cur_obs = cur_pts = cur_cams = 0;
-        obs_base = next_obs;
-    };
-    std::vector<int32_t> fidx;
-    for (int i = 0; i < s.n_pts_chunked; ++i) {
-        const int64_t b = pstart[i], e = pstart[i + 1];
-        const int L = (int)(e - b);
-        fidx.resize(L);
-        for (int a = 0; a < L; ++a) fidx[a] = s.cam_free[s.o_cam[b + a]];
-        bool cut = cur_obs + L > CHUNK_OBS || cur_pts + 1 > CHUNK_PTS;
-        if (!cut && cur_obs >= CHUNK_OBS / 4) {
-            // soft cut: would this point overflow the LDS tiles?
-            int newc = 0, newp = 0;
-            for (int a = 0; a < L; ++a) {
-                if (fidx[a] < 0) continue;
-                bool seen = cam_stamp[fidx[a]] == chunk;
-                for (int a2 = 0; a2 < a && !seen; ++a2) seen = fidx[a2] == fidx[a];
-                if (!seen) ++newc;
-                for (int c = a; c < L; ++c) {
-                    if (fidx[c] < 0) continue;
-                    const int32_t lp = find_pair(fidx[a], fidx[c], chunk);  // (duplicates inside the point over-count: harmless)
-                    if (lp < 0 || pair_cnt[lp] % PAIR_RUN == 0) ++newp;  // opens a new group
-                }
-            }
-            if (cur_cams + newc > CHUNK_CAMS || cur_groups + newp > CHUNK_OBS / 2) cut = true;
-        }
-        if (cut && cur_pts > 0) close_chunk(i, b);
-        for (int a = 0; a < L; ++a) {
-            int f = fidx[a];
-            int16_t slot = -2;
-            if (f >= 0) {
-                if (cam_stamp[f] != chunk) {
-                    cam_stamp[f] = chunk;
-                    if (cur_cams < CHUNK_CAMS) {
-                        cam_slot[f] = cur_cams++;
-                        s.ck_cam_list.push_back(f);
-                    } else {
-                        cam_slot[f] = -1;
-                    }
-                }
-                slot = (int16_t)cam_slot[f];
-                if (slot < 0) {
-                    slot = -1;
-                    s.n_direct_cam_obs++;
-                }
-            }
-            s.o_lcam[b + a] = slot;
-        }
-        for (int a = 0; a < L; ++a) {
-            if (fidx[a] < 0) continue;
-            for (int c = a; c < L; ++c) {
-                if (fidx[c] < 0) continue;
-                int32_t lp = find_pair(fidx[a], fidx[c], chunk);
-                if (lp < 0) {
-                    lp = cur_pairs++;
-                    const int64_t key = ((int64_t)fidx[a] << 32) | (uint32_t)fidx[c];
-                    const int sa = cam_slot[fidx[a]], sc = cam_slot[fidx[c]];
-                    if (sa >= 0 && sc >= 0) {
-                        pair_lut[(size_t)sa * CHUNK_CAMS + sc] = lp;
-                        lut_touched.push_back(sa * CHUNK_CAMS + sc);
-                    } else {
-                        pair_map.emplace(key, lp);
-                    }
-                    ck_pair_key.push_back(key);
-                }
-                const uint32_t oi = (uint32_t)(b + a - obs_base), oj = (uint32_t)(b + c - obs_base);
-                if ((size_t)lp >= pair_cnt.size()) pair_cnt.resize(lp + 1, 0);
-                s.pair_entries.push_back(oi | (oj << 8) | ((uint32_t)lp << 16));
-                if (pair_cnt[lp]++ % PAIR_RUN == 0) ++cur_groups;
-                if (c != a && fidx[c] == fidx[a]) {  // same camera observing the point twice
-                    s.pair_entries.push_back(oj | (oi << 8) | ((uint32_t)lp << 16));
-                    if (pair_cnt[lp]++ % PAIR_RUN == 0) ++cur_groups;
-                }
-            }
-        }
-        cur_obs += L;
-        cur_pts += 1;
+        s.ck_cam_list.insert(s.ck_cam_list.end(), P.ck_cam_list.begin(), P.ck_cam_list.end());
+        ck_pair_key.insert(ck_pair_key.end(), P.keys.begin(), P.keys.end());
+        s.ck_pgrp.insert(s.ck_pgrp.end(), P.ck_pgrp.begin(), P.ck_pgrp.end());
+        s.pair_entries.insert(s.pair_entries.end(), P.pair_entries.begin(), P.pair_entries.end());
+        s.n_pair_real += P.n_pair_real;
+        s.n_direct_pairs += P.n_direct_pairs;
+        s.n_direct_cam_obs += P.n_direct_cam_obs;
+        s.max_chunk_cams = std::max(s.max_chunk_cams, P.max_chunk_cams);
+        s.max_chunk_pairs = std::max(s.max_chunk_pairs, P.max_chunk_pairs);
+        P = Part();
     }
-    if (cur_pts > 0) close_chunk(s.n_pts_chunked, pstart[s.n_pts_chunked]);
     tick("chunking");
     // --- heavy points (more observations than a chunk holds): one workgroup each (k_build_heavy), every (a <= c)
     // pair of the point's observations gets its block slot from a triangular list

@@ -7,6 +7,6 @@ OUT=../libba_hip.so
 mkdir -p build
 $HIPCC -O3 -std=c++17 --offload-arch=gfx950 -munsafe-fp-atomics -fPIC -Wall -Wno-unused-function ${BA_EXTRA_FLAGS} \
     -c ba_engine.hip -o build/ba_engine.o
-g++ -O2 -std=c++17 -fPIC -Wall -c ba_symbolic.cpp -o build/ba_symbolic.o
-$HIPCC --offload-arch=gfx950 -shared -fPIC build/ba_engine.o build/ba_symbolic.o -o $OUT
+g++ -O2 -std=c++17 -fPIC -Wall -pthread -c ba_symbolic.cpp -o build/ba_symbolic.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC build/ba_engine.o build/ba_symbolic.o -lpthread -o $OUT
 echo "built $(realpath $OUT)"
