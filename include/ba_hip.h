@@ -45,7 +45,8 @@ extern "C" {
 /* loss kinds = what scipy.optimize.least_squares accepts (scipy _lsq/least_squares.py:208-209);
  * the reference only uses 'huber' (BundleAdjustment.py:332, :367). */
 enum { BA_LOSS_LINEAR = 0, BA_LOSS_SOFT_L1 = 1, BA_LOSS_HUBER = 2, BA_LOSS_CAUCHY = 3, BA_LOSS_ARCTAN = 4 };
-enum { BA_SOLVER_AUTO = 0, BA_SOLVER_PCG = 1, BA_SOLVER_DENSE_CHOLESKY = 2, BA_SOLVER_BANDED_CHOLESKY = 3 };
+enum { BA_SOLVER_AUTO = 0, BA_SOLVER_PCG = 1, BA_SOLVER_DENSE_CHOLESKY = 2, BA_SOLVER_BANDED_CHOLESKY = 3,
+       BA_SOLVER_CYCLIC_REDUCTION = 4 };
 enum { BA_MEM_HOST = 0, BA_MEM_DEVICE = 1 };
 enum { BA_REDUCE_SUM = 0, BA_REDUCE_MAX = 1, BA_BROADCAST0 = 2 };
 
@@ -76,8 +77,10 @@ typedef struct BaOptions {
     double lambda0;        /* initial LM damping (default 1e-4) */
     double pcg_tol;        /* relative residual of the reduced-camera-system solve (default 1e-8) */
     int32_t pcg_max_iter;  /* default 500 */
-    int32_t linear_solver; /* BA_SOLVER_*: AUTO = dense Cholesky up to 128 free cameras, block-banded Cholesky when
-                              co-visible free cameras are at most 16 apart in camera order, block-Jacobi PCG otherwise */
+    int32_t linear_solver; /* BA_SOLVER_*: AUTO = dense Cholesky up to 128 free cameras; block cyclic reduction when
+                              co-visible free cameras are at most 21 apart in camera order, as a chain or a closed ring;
+                              blocked dense Cholesky for a (nearly) full pattern up to 2048 free cameras; block-Jacobi
+                              PCG otherwise.  BANDED_CHOLESKY (chains, at most 16 apart) only on request */
     int32_t verbose;       /* 0 silent, 1 summary, 2 per-iteration table (<- verbose, :219) */
     int32_t device;        /* HIP device ordinal; -1 = current device */
     int32_t deterministic; /* reserved (0) */

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libba_hip.so")
 BA_OK = 0
 BA_ERR_INVALID = -1
 LOSS = {"linear": 0, "soft_l1": 1, "huber": 2, "cauchy": 3, "arctan": 4}
-SOLVER = {"auto": 0, "pcg": 1, "dense_cholesky": 2, "banded_cholesky": 3}
+SOLVER = {"auto": 0, "pcg": 1, "dense_cholesky": 2, "banded_cholesky": 3, "cyclic_reduction": 4}
 MEM_HOST, MEM_DEVICE = 0, 1
 REDUCE_SUM, REDUCE_MAX, BROADCAST0 = 0, 1, 2
 

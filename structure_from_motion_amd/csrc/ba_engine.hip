@@ -19,6 +19,7 @@
 
 #include "../../include/ba_hip.h"
 #include "ba_banded.h"
+#include "ba_bcr.h"
 #include "ba_dense.h"
 #include "ba_dense_big.h"
 #include "ba_kernels.h"
@@ -259,6 +260,11 @@ struct BaHandle {
     DevBuf<double> dense_a;          // dense reduced system (one-workgroup solver, or the blocked multi-workgroup one)
     DevBuf<double> dense_linv;       // blocked solver: inverse factors of the diagonal blocks
     DevBuf<double> band_l, band_y, band_g, band_mid;  // block-banded factor, work vectors, separator system
+    BcrPlan bcr_plan;                                  // block cyclic reduction (ba_bcr.h): schedule of this pattern,
+    int bcr_state = 0;                                 //   0 not planned yet, 1 usable, -1 the pattern is no chain / ring
+    DevBuf<int32_t> bcr_tab;                           //   elimination / update / block tables
+    DevBuf<double> bcr_dg, bcr_bv, bcr_linv;           //   diagonal blocks + coupling slots, block vectors, tile inverses
+    size_t bcr_off[5] = {0, 0, 0, 0, 0};               //   offsets of the tables inside bcr_tab
     DevBuf<long long> upper_keys;
     DevBuf<int> dense_info;
     int dense_fallbacks = 0;
@@ -297,6 +303,7 @@ int upload_pattern(BaHandle *h) {
     hipStream_t st = h->stream;
     h->n_upper = (int)s.upper_keys.size();
     h->n_full = (int)s.bsr_col.size();
+    h->bcr_state = 0;   // (the elimination schedule belongs to the pattern)
     const int nf = s.n_free;
     HIPCHK(h->ck_pair_slot.upload(s.ck_pair_slot, st));
     HIPCHK(h->hv_pair_slot.upload(s.hv_pair_slot, st));
@@ -528,6 +535,51 @@ int do_banded(BaHandle *h, bool *launched) {
     return BA_OK;  // (pivot flag: see do_step)
 }
 
+// block cyclic reduction solve of S x = -g_red (chain / ring patterns), launched only.  *usable = false when the
+// pattern has no such schedule (nothing is launched then).
+int bcr_plan_for(BaHandle *h) {
+    if (h->bcr_state != 0) return BA_OK;
+    const Symbolic &s = h->sym;
+    h->bcr_state = -1;
+    if (!bcr_make_plan(s.n_free, s.upper_keys.data(), s.upper_keys.size(), h->bcr_plan)) return BA_OK;
+    const BcrPlan &P = h->bcr_plan;
+    std::vector<int32_t> tab;
+    auto put = [&](const void *src, size_t ints) {
+        const size_t at = tab.size();
+        tab.resize(at + ints + 1);   // (+1: no empty table)
+        if (ints) memcpy(tab.data() + at, src, ints * sizeof(int32_t));
+        return at;
+    };
+    h->bcr_off[0] = put(P.elims.data(), P.elims.size() * sizeof(BcrElim) / 4);
+    h->bcr_off[1] = put(P.ops.data(), P.ops.size() * sizeof(BcrOp) / 4);
+    h->bcr_off[2] = put(P.cam_blk.data(), P.cam_blk.size());
+    h->bcr_off[3] = put(P.edge_slot.data(), P.edge_slot.size());
+    h->bcr_off[4] = put(P.blk_start.data(), P.blk_start.size());
+    HIPCHK(h->bcr_tab.upload(tab, h->stream));
+    HIPCHK(h->bcr_dg.alloc(bcr_matrix_doubles(P)));
+    HIPCHK(h->bcr_bv.alloc(bcr_vec_doubles(P)));
+    HIPCHK(h->bcr_linv.alloc(bcr_linv_doubles(P)));
+    if (h->dense_info.n == 0) HIPCHK(h->dense_info.alloc(1));
+    HIPCHK(bcr_prepare_device(P.nt));
+    h->bcr_state = 1;
+    return BA_OK;
+}
+int do_bcr(BaHandle *h, bool *launched) {
+    *launched = false;
+    if (h->sym.n_free == 0 || h->bcr_state != 1) return BA_OK;
+    *launched = true;
+    const int32_t *t = h->bcr_tab.p;
+    BcrDev d{};
+    d.elims = reinterpret_cast<const BcrElim *>(t + h->bcr_off[0]);
+    d.ops = reinterpret_cast<const BcrOp *>(t + h->bcr_off[1]);
+    d.cam_blk = t + h->bcr_off[2];
+    d.edge_slot = t + h->bcr_off[3];
+    d.blk_start = t + h->bcr_off[4];
+    d.DG = h->bcr_dg.p; d.bv = h->bcr_bv.p; d.linv = h->bcr_linv.p; d.info = h->dense_info.p;
+    HIPCHK(bcr_solve_launch(h->stream, h->bcr_plan, d, h->n_upper, h->upper_keys.p, h->S, h->gred, h->px.p));
+    return BA_OK;  // (pivot flag: see do_step)
+}
+
 // the part of a trial step behind the linear solve: camera update, back-substitution + trial cost, reductions, decision
 int step_tail(BaHandle *h, const int *solve_info) {
     hipStream_t st = h->stream;
@@ -578,8 +630,16 @@ int do_step(BaHandle *h) {
     // "a genuine dense contraction": at least a quarter of the 6x6 blocks of S are there (every camera shares landmarks
     // with most others); a sparse S of that size is cheaper through PCG
     const bool dense_pattern = (double)h->n_full >= 0.25 * (double)s.n_free * (double)s.n_free;
+    // chain- or ring-shaped co-visibility beyond the one-workgroup dense solver: block cyclic reduction (whole chip)
+    bool can_bcr = false;
+    if ((ls == BA_SOLVER_CYCLIC_REDUCTION || (ls == BA_SOLVER_AUTO && !can_dense)) && s.n_free > 0) {
+        if ((e = bcr_plan_for(h))) return e;
+        can_bcr = h->bcr_state == 1;
+    }
     if ((ls == BA_SOLVER_AUTO || ls == BA_SOLVER_DENSE_CHOLESKY) && can_dense) {
         if ((e = do_dense(h, &direct))) return e;
+    } else if (can_bcr) {
+        if ((e = do_bcr(h, &direct))) return e;
     } else if ((ls == BA_SOLVER_AUTO || ls == BA_SOLVER_BANDED_CHOLESKY) && can_band) {
         if ((e = do_banded(h, &direct))) return e;
     } else if (can_big && (ls == BA_SOLVER_DENSE_CHOLESKY || (ls == BA_SOLVER_AUTO && dense_pattern))) {
@@ -695,6 +755,7 @@ int alloc_work(BaHandle *h) {
     // solver work space is sized on first use: drop what belonged to another structure
     h->dense_a.release(); h->dense_linv.release();
     h->band_l.release(); h->band_y.release(); h->band_g.release(); h->band_mid.release();
+    h->bcr_tab.release(); h->bcr_dg.release(); h->bcr_bv.release(); h->bcr_linv.release();
     h->dbg_v.release(); h->dbg_gp.release();
     h->pattern_uploaded = false;
     return BA_OK;

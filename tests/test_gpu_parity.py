@@ -307,6 +307,70 @@ def test_blocked_dense_cholesky_at_ladybug_size(gpu):
     print("3 LM steps at 10326 unknowns: banded %.1f ms, blocked dense %.1f ms" % (sb["t_solve_ms"], sd["t_solve_ms"]))
 
 
+def _lm_paths(p, solvers, max_iter, **kw):
+    out = {}
+    for solver in solvers:
+        arr = _capi.Arrays.from_dict(p)
+        out[solver] = (_capi.solve(arr, loss="huber", f_scale=1.0, max_iter=max_iter, linear_solver=solver, **kw), arr)
+    return out
+
+
+def test_cyclic_reduction_matches_the_other_direct_solvers_on_chains(gpu):
+    """Block cyclic reduction (ba_bcr.h) is a Cholesky factorisation in odd-even order: same LM path as the dense /
+    banded factorisations.  Street chains with co-visibility windows of 16, 9 and 4 cameras = blocks of 96, 64 and 32
+    scalars (6, 4 and 2 MFMA tiles), one of them with a ragged last block."""
+    for nc, n_pts, n_obs, mt, seed, other in ((90, 2500, 11000, 16, 21, "dense_cholesky"), (203, 5000, 22000, 16, 51, "banded_cholesky"),
+                                              (120, 3000, 10000, 9, 61, "dense_cholesky"), (101, 3000, 8000, 4, 62, "dense_cholesky")):
+        p = synthetic.make_street(nc, n_pts, n_obs, seed=seed, outlier_frac=0.01, max_track=mt)
+        out = _lm_paths(p, ("cyclic_reduction", other), 15)
+        sc, so = out["cyclic_reduction"][0], out[other][0]
+        assert sc["pcg_iterations"] == 0 and so["pcg_iterations"] == 0, (nc, mt)          # neither fell back
+        assert sc["iterations"] == so["iterations"] and sc["accepted"] == so["accepted"], (nc, mt)
+        assert so["final_cost"] < 0.05 * so["initial_cost"]
+        assert abs(sc["final_cost"] - so["final_cost"]) <= 1e-9 * so["final_cost"], (nc, mt)
+        np.testing.assert_allclose(out["cyclic_reduction"][1].cam_pose, out[other][1].cam_pose, rtol=1e-6, atol=1e-7)
+
+
+def test_cyclic_reduction_on_a_closed_ring(gpu):
+    """Loop closure: the last cameras of the ring see what the first ones see, so S has corner blocks and no small
+    bandwidth in any camera order.  Cyclic reduction solves it directly (the ring of blocks is halved per level); same
+    LM path as the dense factorisation, and AUTO picks it (no PCG iterations) once the system is beyond the one-workgroup
+    dense solver."""
+    p = synthetic.make_ring(120, 6000, seed=71, mean_track=5.0, max_track=9, n_fixed=2, outlier_frac=0.01)
+    out = _lm_paths(p, ("cyclic_reduction", "dense_cholesky"), 15)
+    sc, sd = out["cyclic_reduction"][0], out["dense_cholesky"][0]
+    assert sc["pcg_iterations"] == 0 and sd["pcg_iterations"] == 0
+    assert sc["iterations"] == sd["iterations"] and sc["accepted"] == sd["accepted"] and sd["accepted"] >= 3
+    assert abs(sc["final_cost"] - sd["final_cost"]) <= 1e-9 * sd["final_cost"]
+    np.testing.assert_allclose(out["cyclic_reduction"][1].cam_pose, out["dense_cholesky"][1].cam_pose, rtol=1e-6, atol=1e-7)
+    # 400 cameras (2388 unknowns), windows up to 18 cameras: blocks of 128 scalars; AUTO against a tight PCG
+    p = synthetic.make_ring(400, 20000, seed=72, mean_track=6.0, max_track=18, n_fixed=2, outlier_frac=0.01, radius=60.0,
+                            point_radius=(4.0, 20.0))
+    out = _lm_paths(p, ("auto", "pcg"), 12, pcg_tol=1e-12, pcg_max_iter=2000)
+    sa, sp = out["auto"][0], out["pcg"][0]
+    assert sa["pcg_iterations"] == 0 and sp["pcg_iterations"] > 0
+    assert sa["accepted"] >= 3 and sa["final_cost"] < 0.2 * sa["initial_cost"]
+    assert abs(sa["final_cost"] - sp["final_cost"]) <= 1e-6 * sp["final_cost"]
+    np.testing.assert_allclose(out["auto"][1].cam_pose, out["pcg"][1].cam_pose, rtol=1e-4, atol=1e-5)
+
+
+def test_cyclic_reduction_requested_on_a_pattern_without_a_schedule(gpu, monkeypatch):
+    """Landmarks seen by every camera make S full: no chain / ring schedule, the request falls through to PCG.  And a
+    bad pivot inside the cyclic reduction voids the step like in the other direct solvers."""
+    p = synthetic.make_ring(40, 1500, seed=73, mean_track=4.0, n_fixed=2, n_landmarks=20)
+    out = _lm_paths(p, ("cyclic_reduction", "pcg"), 10, pcg_tol=1e-10)
+    assert out["cyclic_reduction"][0]["pcg_iterations"] == out["pcg"][0]["pcg_iterations"] > 0
+    assert out["cyclic_reduction"][0]["final_cost"] == pytest.approx(out["pcg"][0]["final_cost"], rel=1e-9)
+    p = synthetic.make_street(30, 800, 3500, seed=33, outlier_frac=0.02)
+    a1, a2 = _capi.Arrays.from_dict(p), _capi.Arrays.from_dict(p)
+    s_pcg = _capi.solve(a1, loss="huber", f_scale=1.0, max_iter=30, linear_solver="pcg", pcg_tol=1e-10)
+    monkeypatch.setenv("BA_DEBUG_FAIL_DIRECT", "1")
+    s_fb = _capi.solve(a2, loss="huber", f_scale=1.0, max_iter=30, linear_solver="cyclic_reduction", pcg_tol=1e-10)
+    monkeypatch.delenv("BA_DEBUG_FAIL_DIRECT")
+    assert s_fb["pcg_iterations"] > 0 and s_fb["iterations"] == s_pcg["iterations"]
+    assert abs(s_fb["final_cost"] - s_pcg["final_cost"]) <= 1e-9 * s_pcg["final_cost"]
+
+
 def test_set_values_reuses_the_structure(gpu):
     """SURVEY 8(f) f1 (device-resident reuse): ba_set_values on a handle that has already solved problem A gives,
     for new values B on the same structure, the reduced system and the solution of a fresh handle on B; a problem
