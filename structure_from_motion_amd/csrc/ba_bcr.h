@@ -44,6 +44,9 @@ namespace ba {
 struct BcrElim { int32_t k, gu, gv, u, v; };                       // block, coupling slots (-1: none), neighbour blocks
 struct BcrOp { int32_t kind, dst, a0, b0, a1, b1, k0, k1, init; };  // kind 0: D[dst] -= W[a0] W[a0]^T (+ a1), b[dst] -= W[a0] y[k0] (+ ..)
                                                                     // kind 1: G[dst] (init: = 0) -= W[a0] W[b0]^T (+ W[a1] W[b1]^T)
+constexpr int32_t BCR_SRC_TRANSPOSED = 1 << 30, BCR_SRC_SYMMETRISE = 1 << 29, BCR_SRC_MASK = (1 << 29) - 1;
+constexpr int32_t BCR_SRC_ZERO = -1, BCR_SRC_UNIT = -2;
+
 struct BcrPlan {
     bool ok = false, cyclic = false;
     int nf = 0, m = 0, nt = 0, nb = 0, band = 0, n_slots = 0, n_init_slots = 0;
@@ -51,6 +54,8 @@ struct BcrPlan {
     std::vector<int32_t> cam_blk;    // [nf] block << 8 | offset inside the block
     std::vector<int32_t> edge_slot;  // [m] slot of the coupling between block b and b + 1 (entry m - 1: the ring's corner
                                      // block, between 0 and m - 1) | bit 30: rows belong to the higher block; -1: none
+    std::vector<int32_t> src;        // [(m + n_init_slots) * cbt * cbt], cbt = nb / 6: per 6x6 block of the diagonal blocks and
+                                     // the initial coupling slots, where it comes from: slot of S | BCR_SRC_*, or BCR_SRC_ZERO / _UNIT
     std::vector<int32_t> lvl_elim, lvl_op;  // [levels + 1] offsets into elims / ops
     std::vector<BcrElim> elims;
     std::vector<BcrOp> ops;
@@ -191,6 +196,22 @@ inline bool bcr_make_plan(int nf, const int64_t *keys, size_t nk, BcrPlan &P) {
         P.lvl_elim.push_back((int32_t)P.elims.size());
         P.lvl_op.push_back((int32_t)P.ops.size());
     }
+    // where every 6x6 block of the diagonal blocks / initial coupling slots comes from
+    const int cbt = P.nb / 6;
+    P.src.assign((size_t)(m + P.n_init_slots) * cbt * cbt, BCR_SRC_ZERO);
+    for (int b = 0; b < m; ++b)   // padding cameras: unit diagonal
+        for (int o = start[b + 1] - start[b]; o < cbt; ++o) P.src[((size_t)b * cbt + o) * cbt + o] = BCR_SRC_UNIT;
+    for (size_t q = 0; q < nk; ++q) {
+        const int i = (int)(keys[q] >> 32), j = (int)(keys[q] & 0xffffffff);
+        const int bi = P.cam_blk[i] >> 8, oi = P.cam_blk[i] & 255, bj = P.cam_blk[j] >> 8, oj = P.cam_blk[j] & 255;
+        if (bi == bj) {   // lower triangle: row = camera j, column = camera i  ->  S_ij transposed
+            P.src[((size_t)bi * cbt + oj) * cbt + oi] = (int32_t)q | (i == j ? BCR_SRC_SYMMETRISE : BCR_SRC_TRANSPOSED);
+        } else {          // camera i sits in the lower-numbered block of the edge
+            const int es = P.edge_slot[bj == bi + 1 ? bi : m - 1], slot = es & 0x3fffffff;
+            if (es >> 30 & 1) P.src[((size_t)(m + slot) * cbt + oj) * cbt + oi] = (int32_t)q | BCR_SRC_TRANSPOSED;
+            else P.src[((size_t)(m + slot) * cbt + oi) * cbt + oj] = (int32_t)q;
+        }
+    }
     P.ok = true;
     return true;
 }
@@ -198,54 +219,58 @@ inline bool bcr_make_plan(int nf, const int64_t *keys, size_t nk, BcrPlan &P) {
 inline size_t bcr_matrix_doubles(const BcrPlan &P) { return (size_t)(P.m + P.n_slots) * P.nb * P.nb; }
 inline size_t bcr_vec_doubles(const BcrPlan &P) { return (size_t)P.m * P.nb; }
 inline size_t bcr_linv_doubles(const BcrPlan &P) { return (size_t)P.m * P.nt * 256; }
+inline size_t bcr_back_lds_bytes(int nt) {
+    const int nb = 16 * nt;
+    return ((size_t)nb * nb + (size_t)nt * 256 + (size_t)(512 / nb) * nb + nb + 16) * sizeof(double);
+}
 inline size_t bcr_factor_lds_bytes(int nt) {
     const int nb = 16 * nt;
     return ((size_t)(nb + 1) * (nb + 1) + 16 * 17 + (size_t)nt * 16 * 17) * sizeof(double);
 }
 
 // ------------------------------------------------------------------------------------------------ assembly
-// S (upper 6x6 blocks, keys (i << 32 | j), i <= j) -> diagonal blocks D (lower triangle) and the initial coupling slots
-__global__ void k_bcr_assemble(int n_upper, const long long *__restrict__ keys, const double *__restrict__ S,
-                               const int32_t *__restrict__ cam_blk, const int32_t *__restrict__ edge_slot, int m, int NB,
-                               double *__restrict__ D, double *__restrict__ G) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n_upper * 36) return;
-    const int k = e / 36, ab = e - k * 36, a = ab / 6, b = ab - a * 6;
-    const int i = (int)(keys[k] >> 32), j = (int)(keys[k] & 0xffffffffLL);
-    const int ci = cam_blk[i], cj = cam_blk[j];
-    const int bi = ci >> 8, oi = ci & 255, bj = cj >> 8, oj = cj & 255;
-    const double v = S[e];
+// One pass writes EVERY element of the diagonal blocks and the initial coupling slots -- from its 6x6 block of S (upper
+// blocks, row-major), zero, or the unit diagonal of the padding -- plus the right-hand side b = -g per block and the pivot
+// flag.  (A memset of the blocks followed by a scatter of S took two fills and two kernels with their launch gaps: 60 us
+// in front of a 400 us solve.)
+__global__ void k_bcr_gather(int n_blocks, int m, int NB, const int32_t *__restrict__ src, const double *__restrict__ S,
+                             const int32_t *__restrict__ blk_start, const double *__restrict__ g, double *__restrict__ DG,
+                             double *__restrict__ bv, int *__restrict__ info) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t nb2 = (size_t)NB * NB;
-    if (bi == bj) {
-        if (i == j) {
-            if (a >= b) D[bi * nb2 + (size_t)(oi * 6 + a) * NB + oi * 6 + b] = 0.5 * (v + S[(size_t)k * 36 + b * 6 + a]);
-        } else {
-            D[bi * nb2 + (size_t)(oj * 6 + b) * NB + oi * 6 + a] = v;   // lower block (j, i) = upper block transposed
+    if (t == 0) *info = 0;
+    if (t < (size_t)m * NB) {
+        const int b = (int)(t / NB), o = (int)(t - (size_t)b * NB), sz = 6 * (blk_start[b + 1] - blk_start[b]);
+        bv[t] = o < sz ? -g[(size_t)6 * blk_start[b] + o] : 0.0;
+    }
+    if (t >= (size_t)n_blocks * nb2) return;
+    const int blk = (int)(t / nb2), e = (int)(t - blk * nb2), r = e / NB, c = e - r * NB;
+    const int cbt = NB / 6, ro = r / 6, a = r - ro * 6, co = c / 6, b = c - co * 6;
+    double v = 0.0;
+    if (ro >= cbt || co >= cbt) {
+        v = (r == c && blk < m) ? 1.0 : 0.0;   // (rows / columns behind the last whole camera)
+    } else {
+        const int32_t sc = src[((size_t)blk * cbt + ro) * cbt + co];
+        if (sc == BCR_SRC_UNIT) {
+            v = a == b ? 1.0 : 0.0;
+        } else if (sc >= 0) {
+            const double *sb = S + (size_t)(sc & BCR_SRC_MASK) * 36;
+            if (sc & BCR_SRC_SYMMETRISE) v = 0.5 * (sb[a * 6 + b] + sb[b * 6 + a]);
+            else if (sc & BCR_SRC_TRANSPOSED) v = sb[b * 6 + a];
+            else v = sb[a * 6 + b];
         }
-    } else {
-        const int es = edge_slot[bj == bi + 1 ? bi : m - 1];   // camera i sits in the lower-numbered block of the edge
-        double *g = G + (size_t)(es & 0x3fffffff) * nb2;
-        if (es >> 30 & 1) g[(size_t)(oj * 6 + b) * NB + oi * 6 + a] = v;
-        else g[(size_t)(oi * 6 + a) * NB + oj * 6 + b] = v;
     }
-}
-
-// right-hand side b = -g per block, unit diagonal and zero right-hand side in the padding of each block
-__global__ void k_bcr_init(int m, int NB, const int32_t *__restrict__ blk_start, const double *__restrict__ g,
-                           double *__restrict__ D, double *__restrict__ bv) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= m * NB) return;
-    const int b = t / NB, o = t - b * NB, sz = 6 * (blk_start[b + 1] - blk_start[b]);
-    if (o < sz) {
-        bv[t] = -g[(size_t)6 * blk_start[b] + o];
-    } else {
-        bv[t] = 0.0;
-        D[(size_t)b * NB * NB + (size_t)o * NB + o] = 1.0;
-    }
+    DG[t] = v;
 }
 
 // ------------------------------------------------------------------------------------------------ factor
 #define BA_BCR_DWAVES 4
+#ifdef BA_BCR_TIMING   // tools/bcr_bench.hip: cycle stamps of workgroup 0 (wave, stamp)
+__device__ long long g_bcr_t[16 * 40];
+#define BCR_STAMP(k) do { if (blockIdx.x == 0 && lane == 0) g_bcr_t[wv * 40 + (k)] = clock64(); } while (0)
+#else
+#define BCR_STAMP(k) do { } while (0)
+#endif
 // compile-time loop (the step index selects accumulator registers: the loop has to be unrolled whatever its size)
 template <int I, int N, class F>
 __device__ __forceinline__ void bcr_static_for(F &&f) {
@@ -254,6 +279,52 @@ __device__ __forceinline__ void bcr_static_for(F &&f) {
         bcr_static_for<I + 1, N>(f);
     }
 }
+// Cholesky factor of one 16x16 diagonal tile and the inverse of the factor, by ONE wave (lanes 16.. mirror lanes 0..15):
+// lane r holds row r of the tile in registers AND column r of the inverse; the pivot column's entries L[c][j] travel by
+// readlane (two per double, ~12 cycles each: they, not the arithmetic, set the time), so every broadcast entry is used
+// twice -- for the trailing update  A[r][c] -= L[r][j] L[c][j]  and for the forward substitution of the inverse
+// X = L^-1:  x_j = (delta_j,lane - s_j) / L[j][j],  s_c += L[c][j] x_j  (10.4 k cycles per tile with two separate passes).
+// dt: this lane's row of the tile in LDS (in: A, out: L); sLinv: 16 x 17 in LDS; li: 16 x 16 in global memory or null.
+__device__ __forceinline__ int bcr_potrf16(double *dt, double *sLinv, double *li, int lane) {
+    const int l15 = lane & 15;
+    int bad = 0;
+    double row[16], x[16], sacc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { row[c] = dt[c]; sacc[c] = 0.0; }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        double d = band_readlane(row[j], j);
+        asm volatile("" : "+v"(d));   // (tested in vector registers: as a scalar the flag of every column stays live)
+        if (!(d > 0.0)) bad = 1;
+        const double inv = band_rsqrt(d > 0.0 ? d : 1.0);
+        row[j] *= inv;
+        const double xj = ((j == l15 ? 1.0 : 0.0) - sacc[j]) * inv;
+        x[j] = xj;
+#pragma unroll
+        for (int c = j + 1; c < 16; ++c) {
+            const double lc = band_readlane(row[j], c);   // L[c][j]
+            row[c] = fma(-row[j], lc, row[c]);
+            sacc[c] = fma(lc, xj, sacc[c]);
+            // (pinned here: left alone, the optimiser sinks these updates to where row[c] is next read -- a left-looking
+            // sweep that keeps every L[c][j] of the tile in scalar registers; they do not fit and get spilled to and
+            // reloaded from VGPR lanes, 1200 extra lane moves per tile)
+            asm volatile("" : "+v"(row[c]), "+v"(sacc[c]));
+        }
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (c <= l15) dt[c] = row[c];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sLinv[r * 17 + l15] = x[r];
+        if (li) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) li[r * 16 + l15] = x[r];
+        }
+    }
+    return bad;
+}
+
 template <int NT>
 __global__ __launch_bounds__(64 * (NT + BA_BCR_DWAVES)) void k_bcr_factor(const BcrElim *__restrict__ elims, double *__restrict__ D,
                                                                          double *__restrict__ G, double *__restrict__ bv,
@@ -288,141 +359,129 @@ __global__ __launch_bounds__(64 * (NT + BA_BCR_DWAVES)) void k_bcr_factor(const 
 #pragma unroll
             for (int v = 0; v < 4; ++v) acc[c][v] = Gs[(size_t)(sr * 16 + l4 + 4 * v) * NB + c * 16 + l15];
     }
+    BCR_STAMP(0);
     __syncthreads();
+    BCR_STAMP(1);
     int bad = 0;
     double aW[4] = {0.0, 0.0, 0.0, 0.0};
-    bcr_static_for<0, NT>([&](auto step_c) {
-        constexpr int s = decltype(step_c)::value;
-        // ---- A: wave 0 factors the diagonal tile (s, s) and inverts its factor (lanes 16.. mirror lanes 0..15)
-        if (wv == 0) {
-            double row[16], invd[16];
-            double *dt = &sD[(16 * s + l15) * LDD + 16 * s];
+    // one 16x16 tile task of the D-waves: (i, s) <- (i, s) Linv^T (panel), or (i, j) -= (i, s) (j, s)^T (trailing);
+    // tile row NT is the right-hand-side row (sixteen copies of it as the MFMA operand, row 0 of the result kept)
+    auto panel_tile = [&](int i, int s) {
+        const int arow = i < NT ? 16 * i + l15 : NB;
+        mfma_d4 w = mfma_d4{0.0, 0.0, 0.0, 0.0};
+        double aq[4], bq[4];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) row[c] = dt[c];
+        for (int q = 0; q < 4; ++q) { aq[q] = sD[arow * LDD + 16 * s + 4 * q + l4]; bq[q] = sLinv[l15 * 17 + 4 * q + l4]; }
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const double d = band_readlane(row[j], j);
-                if (!(d > 0.0)) bad = 1;
-                const double inv = band_rsqrt(d > 0.0 ? d : 1.0);
-                invd[j] = inv;
-                row[j] *= inv;
+        for (int q = 0; q < 4; ++q) w = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[q], bq[q], w, 0, 0, 0);
+        if (i < NT) {
 #pragma unroll
-                for (int c = j + 1; c < 16; ++c) row[c] = fma(-row[j], band_readlane(row[j], c), row[c]);
-            }
-            if (lane < 16) {
-#pragma unroll
-                for (int c = 0; c < 16; ++c)
-                    if (c <= l15) dt[c] = row[c];
-            }
-            // X = L^-1, lane = column: x_r = (delta_rc - sum_{k<r} L[r][k] x_k) / L[r][r]
-            double x[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                double sum = (r == l15) ? 1.0 : 0.0;
-#pragma unroll
-                for (int k = 0; k < r; ++k) sum = fma(-band_readlane(row[k], r), x[k], sum);
-                x[r] = sum * invd[r];
-            }
-            if (lane < 16) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sLinv[r * 17 + l15] = x[r];
-                if (side == 0) {
-                    double *li = Linv16 + ((size_t)el.k * NT + s) * 256;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) li[r * 16 + l15] = x[r];
-                }
-            }
+            for (int v = 0; v < 4; ++v) sD[(16 * i + l4 + 4 * v) * LDD + 16 * s + l15] = w[v];
+        } else if (l4 == 0) {
+            sD[NB * LDD + 16 * s + l15] = w[0];
         }
-        __syncthreads();
-        // ---- B: panel tiles (i, s) <- (i, s) Linv^T; the strips turn their tile s into W_s
-        if (wv < BA_BCR_DWAVES) {
-            double bq[4];
+    };
+    auto trailing_tile = [&](int i, int j, int s) {
+        const int arow = i < NT ? 16 * i + l15 : NB;
+        double aq[4], bq[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) bq[q] = sLinv[l15 * 17 + 4 * q + l4];
-#pragma unroll
-            for (int i = s + 1; i <= NT; ++i) {
-                if ((i - s - 1) % BA_BCR_DWAVES != wv) continue;
-                const int arow = i < NT ? 16 * i + l15 : NB;   // (tile NT: sixteen copies of the right-hand-side row)
-                mfma_d4 w = mfma_d4{0.0, 0.0, 0.0, 0.0};
-                double aq[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) aq[q] = sD[arow * LDD + 16 * s + 4 * q + l4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) w = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[q], bq[q], w, 0, 0, 0);
-                if (i < NT) {
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) sD[(16 * i + l4 + 4 * v) * LDD + 16 * s + l15] = w[v];
-                } else if (l4 == 0) {
-                    sD[NB * LDD + 16 * s + l15] = w[0];
-                }
-            }
-        } else if (strip) {
-#pragma unroll
-            for (int v = 0; v < 4; ++v) stg[(l4 + 4 * v) * 17 + l15] = acc[s][v];
-            band_wave_sync();
-            double aq[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) aq[q] = stg[l15 * 17 + 4 * q + l4];
-            mfma_d4 w = mfma_d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) w = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[q], sLinv[l15 * 17 + 4 * q + l4], w, 0, 0, 0);
-            acc[s] = w;
-            band_wave_sync();
-#pragma unroll
-            for (int v = 0; v < 4; ++v) stg[(l4 + 4 * v) * 17 + l15] = w[v];
-            band_wave_sync();
-#pragma unroll
-            for (int q = 0; q < 4; ++q) aW[q] = -stg[l15 * 17 + 4 * q + l4];
+        for (int q = 0; q < 4; ++q) {
+            aq[q] = -sD[arow * LDD + 16 * s + 4 * q + l4];
+            bq[q] = sD[(16 * j + l15) * LDD + 16 * s + 4 * q + l4];
         }
-        __syncthreads();
-        // ---- C: trailing tiles (i, j) -= (i, s) (j, s)^T.  Wave 0 takes (s+1, s+1) only and goes on to factor it while
-        //         the other waves finish (no barrier between C and the next A)
-        if (s + 1 < NT) {
+        mfma_d4 w;
+        if (i < NT) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) w[v] = sD[(16 * i + l4 + 4 * v) * LDD + 16 * j + l15];
+        } else {
+            w = mfma_d4{sD[NB * LDD + 16 * j + l15], 0.0, 0.0, 0.0};
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[q], bq[q], w, 0, 0, 0);
+        if (i < NT) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) sD[(16 * i + l4 + 4 * v) * LDD + 16 * j + l15] = w[v];
+        } else if (l4 == 0) {
+            sD[NB * LDD + 16 * j + l15] = w[0];
+        }
+    };
+    // Two barriers per 16-column step s: B1 releases the factor + inverse of tile (s, s), B2 the panel (i, s).
+    // Wave 0 owns the serial chain and nothing else: factor (s, s) | B1 | its own panel tile (s+1, s) and the update of
+    // (s+1, s+1) | B2 | factor (s+1, s+1) ... -- the next diagonal tile is being factored while the other waves still
+    // apply step s.  (A code path of its own also keeps the other waves' addresses out of its scalar registers.)
+    if (wv == 0) {
+        bcr_static_for<0, NT>([&](auto step_c) {
+            constexpr int s = decltype(step_c)::value;
+            if (bcr_potrf16(&sD[(16 * s + l15) * LDD + 16 * s], sLinv, side == 0 ? Linv16 + ((size_t)el.k * NT + s) * 256 : nullptr, lane))
+                bad = 1;
+            BCR_STAMP(2 + 4 * s);
+            __syncthreads();
+            BCR_STAMP(3 + 4 * s);
+            panel_tile(s + 1, s);   // (s + 1 == NT: the right-hand-side row)
+            if (s + 1 < NT) {
+                band_wave_sync();
+                trailing_tile(s + 1, s + 1, s);
+            }
+            BCR_STAMP(4 + 4 * s);
+            __syncthreads();
+            BCR_STAMP(5 + 4 * s);
+        });
+    } else {
+        bcr_static_for<0, NT>([&](auto step_c) {
+            constexpr int s = decltype(step_c)::value;
+            BCR_STAMP(2 + 4 * s);
+            __syncthreads();
+            BCR_STAMP(3 + 4 * s);
             if (wv < BA_BCR_DWAVES) {
-                int task = 0;
 #pragma unroll
-                for (int i = s + 1; i <= NT; ++i) {
-#pragma unroll
-                    for (int j = s + 1; j < NT; ++j) {
-                        if (j > i) continue;
-                        bool mine;
-                        if (i == s + 1 && j == s + 1) mine = wv == 0;
-                        else { mine = wv == 1 + task % (BA_BCR_DWAVES - 1); ++task; }
-                        if (!mine) continue;
-                        const int arow = i < NT ? 16 * i + l15 : NB;
-                        double aq[4], bq[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            aq[q] = -sD[arow * LDD + 16 * s + 4 * q + l4];
-                            bq[q] = sD[(16 * j + l15) * LDD + 16 * s + 4 * q + l4];
-                        }
-                        mfma_d4 w;
-                        if (i < NT) {
-#pragma unroll
-                            for (int v = 0; v < 4; ++v) w[v] = sD[(16 * i + l4 + 4 * v) * LDD + 16 * j + l15];
-                        } else {
-                            w = mfma_d4{sD[NB * LDD + 16 * j + l15], 0.0, 0.0, 0.0};
-                        }
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) w = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[q], bq[q], w, 0, 0, 0);
-                        if (i < NT) {
-#pragma unroll
-                            for (int v = 0; v < 4; ++v) sD[(16 * i + l4 + 4 * v) * LDD + 16 * j + l15] = w[v];
-                        } else if (l4 == 0) {
-                            sD[NB * LDD + 16 * j + l15] = w[0];
-                        }
-                    }
-                }
+                for (int i = s + 2; i <= NT; ++i)
+                    if ((i - s - 2) % (BA_BCR_DWAVES - 1) == wv - 1) panel_tile(i, s);
             } else if (strip) {
 #pragma unroll
-                for (int c = s + 1; c < NT; ++c)
+                for (int v = 0; v < 4; ++v) stg[(l4 + 4 * v) * 17 + l15] = acc[s][v];
+                band_wave_sync();
+                double aq[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(aW[q], sD[(16 * c + l15) * LDD + 16 * s + 4 * q + l4], acc[c], 0, 0, 0);
+                for (int q = 0; q < 4; ++q) aq[q] = stg[l15 * 17 + 4 * q + l4];
+                mfma_d4 w = mfma_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) w = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[q], sLinv[l15 * 17 + 4 * q + l4], w, 0, 0, 0);
+                acc[s] = w;
+                band_wave_sync();
+#pragma unroll
+                for (int v = 0; v < 4; ++v) stg[(l4 + 4 * v) * 17 + l15] = w[v];
+                band_wave_sync();
+#pragma unroll
+                for (int q = 0; q < 4; ++q) aW[q] = -stg[l15 * 17 + 4 * q + l4];
             }
-        }
-    });
+            BCR_STAMP(4 + 4 * s);
+            __syncthreads();
+            BCR_STAMP(5 + 4 * s);
+            if (s + 1 < NT) {
+                if (wv < BA_BCR_DWAVES) {
+                    int task = 0;
+#pragma unroll
+                    for (int i = s + 1; i <= NT; ++i) {
+#pragma unroll
+                        for (int j = s + 1; j < NT; ++j) {
+                            if (j > i || (i == s + 1 && j == s + 1)) continue;   // (wave 0 has done (s+1, s+1))
+                            if (wv == 1 + task % (BA_BCR_DWAVES - 1)) trailing_tile(i, j, s);
+                            ++task;
+                        }
+                    }
+                } else if (strip) {
+#pragma unroll
+                    for (int c = s + 1; c < NT; ++c)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(aW[q], sD[(16 * c + l15) * LDD + 16 * s + 4 * q + l4], acc[c], 0, 0, 0);
+                }
+            }
+        });
+    }
+    BCR_STAMP(2 + 4 * NT);
     __syncthreads();
+    BCR_STAMP(3 + 4 * NT);
     if (strip) {
 #pragma unroll
         for (int c = 0; c < NT; ++c)
@@ -437,40 +496,53 @@ __global__ __launch_bounds__(64 * (NT + BA_BCR_DWAVES)) void k_bcr_factor(const 
         for (int e = tid; e < NB; e += NTHREADS) bv[(size_t)el.k * NB + e] = sD[NB * LDD + e];
         if (wv == 0 && lane == 0 && bad) atomicCAS(info, 0, el.k + 1);
     }
+    BCR_STAMP(4 + 4 * NT);
 }
 
 // ------------------------------------------------------------------------------------------------ update
+// One wave per 16x16 output tile (plus one per 16 rows of the right-hand side), operands straight from L2 / memory.
+// (Measured: fatter waves -- a 16-row strip times half the tile columns per wave, operand rows loaded once -- are
+// slower, 10 instead of 5.5 us on the upper levels: what an update waits for is the latency of its first loads, the
+// blocks were written by other XCDs a kernel ago, and a short wave exposes it once.)
 template <int NT>
-__global__ __launch_bounds__(256) void k_bcr_update(const BcrOp *__restrict__ ops, double *__restrict__ D, double *__restrict__ G,
-                                                    double *__restrict__ bv) {
+__global__ __launch_bounds__(256) void k_bcr_update(int n_ops, const BcrOp *__restrict__ ops, double *__restrict__ D,
+                                                    double *__restrict__ G, double *__restrict__ bv) {
     constexpr int NB = 16 * NT, KQ = NB / 4, TASKS = NT * NT + NT, WGS = (TASKS + 3) / 4;
-    const BcrOp op = ops[blockIdx.x / WGS];
+    // workgroups are dealt round-robin over the 8 XCDs, each with an L2 of its own: renumbered so that the workgroups of
+    // one update (they share its operand blocks) run on ONE XCD
+    const int per_xcd = (n_ops * WGS + 7) / 8;
+    const int wg = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (wg >= n_ops * WGS) return;
+    const BcrOp op = ops[wg / WGS];
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
-    const int task = (blockIdx.x % WGS) * 4 + (tid >> 6);
+    const int task = (wg % WGS) * 4 + (tid >> 6);
     if (task >= TASKS) return;
     const size_t nb2 = (size_t)NB * NB;
     if (task < NT * NT) {
         const int ti = task / NT, tj = task - ti * NT;
         if (op.kind == 0 && tj > ti) return;
+        double *dst = (op.kind == 0 ? D + op.dst * nb2 : G + op.dst * nb2) + (size_t)(ti * 16 + l4) * NB + tj * 16 + l15;
+        double old[4] = {0.0, 0.0, 0.0, 0.0};
+        if (!op.init) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) old[v] = dst[(size_t)4 * v * NB];
+        }
         mfma_d4 w = mfma_d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int sa = q ? op.a1 : op.a0, sb = op.kind == 0 ? sa : (q ? op.b1 : op.b0);
             if (sa < 0) continue;
-            const double *pa = G + sa * nb2 + (size_t)(ti * 16 + l15) * NB + l4 * KQ;
-            const double *pb = G + sb * nb2 + (size_t)(tj * 16 + l15) * NB + l4 * KQ;
+            // lane (row, l4) takes doubles 8 j + 2 l4, + 1 of its row: four lanes read 64 contiguous bytes
+            const double *pa = G + sa * nb2 + (size_t)(ti * 16 + l15) * NB + l4 * 2;
+            const double *pb = G + sb * nb2 + (size_t)(tj * 16 + l15) * NB + l4 * 2;
             double a[KQ], b[KQ];
 #pragma unroll
-            for (int k = 0; k < KQ; ++k) { a[k] = pa[k]; b[k] = pb[k]; }
+            for (int k = 0; k < KQ; ++k) { a[k] = pa[(k >> 1) * 8 + (k & 1)]; b[k] = pb[(k >> 1) * 8 + (k & 1)]; }
 #pragma unroll
             for (int k = 0; k < KQ; ++k) w = __builtin_amdgcn_mfma_f64_16x16x4f64(a[k], b[k], w, 0, 0, 0);
         }
-        double *dst = (op.kind == 0 ? D + op.dst * nb2 : G + op.dst * nb2) + (size_t)(ti * 16 + l4) * NB + tj * 16 + l15;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const double old = op.init ? 0.0 : dst[(size_t)4 * v * NB];
-            dst[(size_t)4 * v * NB] = old - w[v];
-        }
+        for (int v = 0; v < 4; ++v) dst[(size_t)4 * v * NB] = old[v] - w[v];
     } else {
         if (op.kind != 0) return;
         const int ti = task - NT * NT;   // rows 16 ti .. of b[dst]
@@ -479,10 +551,10 @@ __global__ __launch_bounds__(256) void k_bcr_update(const BcrOp *__restrict__ op
         for (int q = 0; q < 2; ++q) {
             const int sa = q ? op.a1 : op.a0, ky = q ? op.k1 : op.k0;
             if (sa < 0) continue;
-            const double *pa = G + sa * nb2 + (size_t)(ti * 16 + l15) * NB + l4 * KQ;
-            const double *py = bv + (size_t)ky * NB + l4 * KQ;
+            const double *pa = G + sa * nb2 + (size_t)(ti * 16 + l15) * NB + l4 * 2;
+            const double *py = bv + (size_t)ky * NB + l4 * 2;
 #pragma unroll
-            for (int k = 0; k < KQ; ++k) s = fma(pa[k], py[k], s);
+            for (int k = 0; k < KQ; ++k) s = fma(pa[(k >> 1) * 8 + (k & 1)], py[(k >> 1) * 8 + (k & 1)], s);
         }
         s += __shfl_xor(s, 16);
         s += __shfl_xor(s, 32);
@@ -497,38 +569,57 @@ __global__ __launch_bounds__(512) void k_bcr_back(const BcrElim *__restrict__ el
                                                   const double *__restrict__ Linv16, const int32_t *__restrict__ blk_start,
                                                   double *__restrict__ xout) {
     constexpr int NB = 16 * NT, PARTS = 512 / NB, RP = (NB + PARTS - 1) / PARTS;
-    __shared__ double sred[PARTS * NB];
-    __shared__ double srhs[NB];
-    __shared__ double sx[16];
+    extern __shared__ double bcr_smem[];
+    double *sL = bcr_smem;             // NB x NB: L_k (every global load of the kernel is issued up front: the blocked
+    double *sLi = sL + NB * NB;        // NT x 256: inverses of its diagonal tiles     substitution below runs out of LDS)
+    double *sred = sLi + NT * 256;     // PARTS x NB
+    double *srhs = sred + PARTS * NB;  // NB
+    double *sx = srhs + NB;            // 16
     const BcrElim el = elims[blockIdx.x];
     const int tid = threadIdx.x;
     const size_t nb2 = (size_t)NB * NB;
+    // (every trip to memory starts here, not behind a barrier)
+    const double yk = tid < NB ? bv[(size_t)el.k * NB + tid] : 0.0;
+    const int c0 = blk_start[el.k], sz = 6 * (blk_start[el.k + 1] - c0);
+    {
+        const double *L = D + el.k * nb2, *li = Linv16 + (size_t)el.k * NT * 256;
+        for (int e = tid; e < NB * NB; e += 512) sL[e] = L[e];
+        for (int e = tid; e < NT * 256; e += 512) sLi[e] = li[e];
+    }
     if (tid < PARTS * NB) {
         const int part = tid / NB, c = tid - part * NB;
-        const int r0 = part * RP, r1 = r0 + RP < NB ? r0 + RP : NB;
+        const int r0 = part * RP;
         double s = 0.0;
-        if (el.gu >= 0) {
-            const double *W = G + el.gu * nb2, *xu = bv + (size_t)el.u * NB;
-            for (int r = r0; r < r1; ++r) s = fma(W[(size_t)r * NB + c], xu[r], s);
-        }
-        if (el.gv >= 0) {
-            const double *W = G + el.gv * nb2, *xv = bv + (size_t)el.v * NB;
-            for (int r = r0; r < r1; ++r) s = fma(W[(size_t)r * NB + c], xv[r], s);
+        // (compile-time trip count: all RP loads of a neighbour are in flight at once -- the blocks were written by other
+        // XCDs, so each load is a trip to memory, and a loop with a run-time bound took them a few at a time)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int g = q ? el.gv : el.gu;
+            if (g < 0) continue;
+            const double *W = G + g * nb2 + (size_t)r0 * NB + c, *xn = bv + (size_t)(q ? el.v : el.u) * NB + r0;
+            double w[RP], xr[RP];
+#pragma unroll
+            for (int i = 0; i < RP; ++i) {
+                const bool in = r0 + i < NB;
+                w[i] = in ? W[(size_t)i * NB] : 0.0;
+                xr[i] = in ? xn[i] : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < RP; ++i) s = fma(w[i], xr[i], s);
         }
         sred[tid] = s;
     }
     __syncthreads();
     if (tid < NB) {
-        double t = bv[(size_t)el.k * NB + tid];
+        double t = yk;
 #pragma unroll
         for (int p = 0; p < PARTS; ++p) t -= sred[p * NB + tid];
         srhs[tid] = t;
     }
     __syncthreads();
-    const double *L = D + el.k * nb2;
     for (int s = NT - 1; s >= 0; --s) {
         if (tid < 16) {
-            const double *li = Linv16 + ((size_t)el.k * NT + s) * 256;   // x_s = Linv_s^T rhs_s
+            const double *li = sLi + s * 256;   // x_s = Linv_s^T rhs_s
             double sum = 0.0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) sum = fma(li[r * 16 + tid], srhs[16 * s + r], sum);
@@ -538,7 +629,7 @@ __global__ __launch_bounds__(512) void k_bcr_back(const BcrElim *__restrict__ el
         if (tid < 16 * s) {
             double sum = 0.0;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) sum = fma(L[(size_t)(16 * s + i) * NB + tid], sx[i], sum);
+            for (int i = 0; i < 16; ++i) sum = fma(sL[(16 * s + i) * NB + tid], sx[i], sum);
             srhs[tid] -= sum;
         } else if (tid < 16 * s + 16) {
             srhs[tid] = sx[tid - 16 * s];
@@ -547,8 +638,7 @@ __global__ __launch_bounds__(512) void k_bcr_back(const BcrElim *__restrict__ el
     }
     if (tid < NB) {
         bv[(size_t)el.k * NB + tid] = srhs[tid];
-        const int sz = 6 * (blk_start[el.k + 1] - blk_start[el.k]);
-        if (tid < sz) xout[(size_t)6 * blk_start[el.k] + tid] = srhs[tid];
+        if (tid < sz) xout[(size_t)6 * c0 + tid] = srhs[tid];
     }
 }
 
@@ -556,7 +646,7 @@ __global__ __launch_bounds__(512) void k_bcr_back(const BcrElim *__restrict__ el
 struct BcrDev {
     const BcrElim *elims;
     const BcrOp *ops;
-    const int32_t *cam_blk, *edge_slot, *blk_start;
+    const int32_t *src, *blk_start;
     double *DG;      // bcr_matrix_doubles: m diagonal blocks, then the coupling slots
     double *bv;      // bcr_vec_doubles
     double *linv;    // bcr_linv_doubles
@@ -565,8 +655,11 @@ struct BcrDev {
 
 template <int NT>
 inline hipError_t bcr_set_attr() {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_bcr_factor<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)bcr_factor_lds_bytes(NT));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bcr_factor<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)bcr_factor_lds_bytes(NT));
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_bcr_back<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)bcr_back_lds_bytes(NT));
 }
 inline hipError_t bcr_prepare_device(int nt) {   // once per device before the first launch (LDS beyond 64 KB)
     switch (nt) {
@@ -578,17 +671,16 @@ inline hipError_t bcr_prepare_device(int nt) {   // once per device before the f
 }
 
 template <int NT>
-inline hipError_t bcr_solve_launch_t(hipStream_t st, const BcrPlan &P, const BcrDev &d, int n_upper, const long long *keys,
-                                     const double *S, const double *g, double *x) {
+inline hipError_t bcr_solve_launch_t(hipStream_t st, const BcrPlan &P, const BcrDev &d, const double *S, const double *g, double *x) {
     constexpr int NB = 16 * NT;
     const size_t nb2 = (size_t)NB * NB;
     double *D = d.DG, *G = d.DG + (size_t)P.m * nb2;
-    hipError_t e;
-    if ((e = hipMemsetAsync(d.DG, 0, (size_t)(P.m + P.n_init_slots) * nb2 * sizeof(double), st)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(d.info, 0, sizeof(int), st)) != hipSuccess) return e;
-    const int ne = n_upper * 36;
-    hipLaunchKernelGGL(k_bcr_assemble, dim3((ne + 255) / 256), dim3(256), 0, st, n_upper, keys, S, d.cam_blk, d.edge_slot, P.m, NB, D, G);
-    hipLaunchKernelGGL(k_bcr_init, dim3((P.m * NB + 255) / 256), dim3(256), 0, st, P.m, NB, d.blk_start, g, D, d.bv);
+    {
+        const int n_blocks = P.m + P.n_init_slots;
+        const size_t n_el = (size_t)n_blocks * nb2;
+        hipLaunchKernelGGL(k_bcr_gather, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, st, n_blocks, P.m, NB, d.src, S, d.blk_start, g,
+                           d.DG, d.bv, d.info);
+    }
     const size_t lds = bcr_factor_lds_bytes(NT);
     constexpr int WGS = (NT * NT + NT + 3) / 4;
     const int nl = P.levels();
@@ -596,23 +688,23 @@ inline hipError_t bcr_solve_launch_t(hipStream_t st, const BcrPlan &P, const Bcr
         const int ne_l = P.lvl_elim[l + 1] - P.lvl_elim[l], no_l = P.lvl_op[l + 1] - P.lvl_op[l];
         hipLaunchKernelGGL(k_bcr_factor<NT>, dim3(2 * ne_l), dim3(64 * (NT + BA_BCR_DWAVES)), lds, st, d.elims + P.lvl_elim[l], D, G,
                            d.bv, d.linv, d.info);
-        if (no_l > 0) hipLaunchKernelGGL(k_bcr_update<NT>, dim3(no_l * WGS), dim3(256), 0, st, d.ops + P.lvl_op[l], D, G, d.bv);
+        if (no_l > 0)
+            hipLaunchKernelGGL(k_bcr_update<NT>, dim3(8 * ((no_l * WGS + 7) / 8)), dim3(256), 0, st, no_l, d.ops + P.lvl_op[l], D, G, d.bv);
     }
     for (int l = nl - 1; l >= 0; --l) {
         const int ne_l = P.lvl_elim[l + 1] - P.lvl_elim[l];
-        hipLaunchKernelGGL(k_bcr_back<NT>, dim3(ne_l), dim3(512), 0, st, d.elims + P.lvl_elim[l], D, G, d.bv, d.linv, d.blk_start, x);
+        hipLaunchKernelGGL(k_bcr_back<NT>, dim3(ne_l), dim3(512), bcr_back_lds_bytes(NT), st, d.elims + P.lvl_elim[l], D, G, d.bv, d.linv, d.blk_start, x);
     }
     return hipGetLastError();
 }
 
 // x = -S^-1 g; *d.info (device) = 0 on success, else 1 + the block whose factorisation met a non-positive pivot
-inline hipError_t bcr_solve_launch(hipStream_t st, const BcrPlan &P, const BcrDev &d, int n_upper, const long long *keys,
-                                   const double *S, const double *g, double *x) {
+inline hipError_t bcr_solve_launch(hipStream_t st, const BcrPlan &P, const BcrDev &d, const double *S, const double *g, double *x) {
     switch (P.nt) {
-        case 2: return bcr_solve_launch_t<2>(st, P, d, n_upper, keys, S, g, x);
-        case 4: return bcr_solve_launch_t<4>(st, P, d, n_upper, keys, S, g, x);
-        case 6: return bcr_solve_launch_t<6>(st, P, d, n_upper, keys, S, g, x);
-        case 8: return bcr_solve_launch_t<8>(st, P, d, n_upper, keys, S, g, x);
+        case 2: return bcr_solve_launch_t<2>(st, P, d, S, g, x);
+        case 4: return bcr_solve_launch_t<4>(st, P, d, S, g, x);
+        case 6: return bcr_solve_launch_t<6>(st, P, d, S, g, x);
+        case 8: return bcr_solve_launch_t<8>(st, P, d, S, g, x);
     }
     return hipErrorInvalidValue;
 }

@@ -264,7 +264,7 @@ struct BaHandle {
     int bcr_state = 0;                                 //   0 not planned yet, 1 usable, -1 the pattern is no chain / ring
     DevBuf<int32_t> bcr_tab;                           //   elimination / update / block tables
     DevBuf<double> bcr_dg, bcr_bv, bcr_linv;           //   diagonal blocks + coupling slots, block vectors, tile inverses
-    size_t bcr_off[5] = {0, 0, 0, 0, 0};               //   offsets of the tables inside bcr_tab
+    size_t bcr_off[4] = {0, 0, 0, 0};                  //   offsets of the tables inside bcr_tab
     DevBuf<long long> upper_keys;
     DevBuf<int> dense_info;
     int dense_fallbacks = 0;
@@ -552,9 +552,8 @@ int bcr_plan_for(BaHandle *h) {
     };
     h->bcr_off[0] = put(P.elims.data(), P.elims.size() * sizeof(BcrElim) / 4);
     h->bcr_off[1] = put(P.ops.data(), P.ops.size() * sizeof(BcrOp) / 4);
-    h->bcr_off[2] = put(P.cam_blk.data(), P.cam_blk.size());
-    h->bcr_off[3] = put(P.edge_slot.data(), P.edge_slot.size());
-    h->bcr_off[4] = put(P.blk_start.data(), P.blk_start.size());
+    h->bcr_off[2] = put(P.src.data(), P.src.size());
+    h->bcr_off[3] = put(P.blk_start.data(), P.blk_start.size());
     HIPCHK(h->bcr_tab.upload(tab, h->stream));
     HIPCHK(h->bcr_dg.alloc(bcr_matrix_doubles(P)));
     HIPCHK(h->bcr_bv.alloc(bcr_vec_doubles(P)));
@@ -572,11 +571,10 @@ int do_bcr(BaHandle *h, bool *launched) {
     BcrDev d{};
     d.elims = reinterpret_cast<const BcrElim *>(t + h->bcr_off[0]);
     d.ops = reinterpret_cast<const BcrOp *>(t + h->bcr_off[1]);
-    d.cam_blk = t + h->bcr_off[2];
-    d.edge_slot = t + h->bcr_off[3];
-    d.blk_start = t + h->bcr_off[4];
+    d.src = t + h->bcr_off[2];
+    d.blk_start = t + h->bcr_off[3];
     d.DG = h->bcr_dg.p; d.bv = h->bcr_bv.p; d.linv = h->bcr_linv.p; d.info = h->dense_info.p;
-    HIPCHK(bcr_solve_launch(h->stream, h->bcr_plan, d, h->n_upper, h->upper_keys.p, h->S, h->gred, h->px.p));
+    HIPCHK(bcr_solve_launch(h->stream, h->bcr_plan, d, h->S, h->gred, h->px.p));
     return BA_OK;  // (pivot flag: see do_step)
 }
 

@@ -44,24 +44,22 @@ int main(int argc, char **argv) {
     if (!ba::bcr_make_plan(N, k64.data(), k64.size(), P)) { printf("no plan for N=%d B=%d ring=%d\n", N, B, ring); return 3; }
     printf("plan: m=%d blocks of %d scalars (nt=%d), band %d, cyclic %d, levels %d, slots %d, elims %zu, ops %zu, LDS %zu B\n", P.m, P.nb, P.nt,
            P.band, (int)P.cyclic, P.levels(), P.n_slots, P.elims.size(), P.ops.size(), ba::bcr_factor_lds_bytes(P.nt));
-    long long *dkeys; double *dS, *dg, *dx;
+    double *dS, *dg, *dx;
     ba::BcrDev d{};
-    ba::BcrElim *delims; ba::BcrOp *dops; int32_t *dcb, *des, *dbs; int *dinfo;
-    CK(hipMalloc(&dkeys, keys.size() * 8)); CK(hipMalloc(&dS, S.size() * 8)); CK(hipMalloc(&dg, n * 8)); CK(hipMalloc(&dx, n * 8));
+    ba::BcrElim *delims; ba::BcrOp *dops; int32_t *dsrc, *dbs; int *dinfo;
+    CK(hipMalloc(&dS, S.size() * 8)); CK(hipMalloc(&dg, n * 8)); CK(hipMalloc(&dx, n * 8));
     CK(hipMalloc(&delims, P.elims.size() * sizeof(ba::BcrElim))); CK(hipMalloc(&dops, (P.ops.size() + 1) * sizeof(ba::BcrOp)));
-    CK(hipMalloc(&dcb, P.cam_blk.size() * 4)); CK(hipMalloc(&des, P.edge_slot.size() * 4)); CK(hipMalloc(&dbs, P.blk_start.size() * 4));
+    CK(hipMalloc(&dsrc, P.src.size() * 4)); CK(hipMalloc(&dbs, P.blk_start.size() * 4));
     CK(hipMalloc(&d.DG, ba::bcr_matrix_doubles(P) * 8)); CK(hipMalloc(&d.bv, ba::bcr_vec_doubles(P) * 8));
     CK(hipMalloc(&d.linv, ba::bcr_linv_doubles(P) * 8)); CK(hipMalloc(&dinfo, 4));
-    CK(hipMemcpy(dkeys, keys.data(), keys.size() * 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(dS, S.data(), S.size() * 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(dg, g.data(), n * 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(delims, P.elims.data(), P.elims.size() * sizeof(ba::BcrElim), hipMemcpyHostToDevice));
     if (!P.ops.empty()) CK(hipMemcpy(dops, P.ops.data(), P.ops.size() * sizeof(ba::BcrOp), hipMemcpyHostToDevice));
-    CK(hipMemcpy(dcb, P.cam_blk.data(), P.cam_blk.size() * 4, hipMemcpyHostToDevice));
-    CK(hipMemcpy(des, P.edge_slot.data(), P.edge_slot.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dsrc, P.src.data(), P.src.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dbs, P.blk_start.data(), P.blk_start.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemset(dx, 0, n * 8));
-    d.elims = delims; d.ops = dops; d.cam_blk = dcb; d.edge_slot = des; d.blk_start = dbs; d.info = dinfo;
+    d.elims = delims; d.ops = dops; d.src = dsrc; d.blk_start = dbs; d.info = dinfo;
     CK(ba::bcr_prepare_device(P.nt));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -69,7 +67,7 @@ int main(int argc, char **argv) {
     for (int it = 0; it < reps + 1; ++it) {
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0));
-        CK(ba::bcr_solve_launch(0, P, d, n_upper, dkeys, dS, dg, dx));
+        CK(ba::bcr_solve_launch(0, P, d, dS, dg, dx));
         CK(hipEventRecord(e1));
         CK(hipDeviceSynchronize());
         float a;
@@ -99,5 +97,18 @@ int main(int argc, char **argv) {
     for (int i = 0; i < n; ++i) { rn += r[i] * r[i]; gn += g[i] * g[i]; xn = std::max(xn, std::fabs(x[i])); }
     const double rel = std::sqrt(rn / gn);
     printf("N=%d B=%d ring=%d info=%d  |Sx+g|/|g| = %.3e (|x|max %.3e)  solve %.3f ms\n", N, B, ring, info, rel, xn, tf / reps);
+#ifdef BA_BCR_TIMING
+    {
+        long long ts[16 * 40];
+        CK(hipMemcpyFromSymbol(ts, HIP_SYMBOL(ba::g_bcr_t), sizeof(ts)));
+        printf("cycle stamps of workgroup 0 of the last factor launch, relative to wave 0 stamp 0\n"
+               "(loaded, barrier | per step: A done, barrier, B done, barrier | C done, barrier, stored):\n");
+        for (int w = 0; w < P.nt + 4; ++w) {
+            printf("  wave %2d:", w);
+            for (int k = 0; k < 5 + 4 * P.nt; ++k) printf(" %6lld", ts[w * 40 + k] ? (ts[w * 40 + k] - ts[0]) : -1);
+            printf("\n");
+        }
+    }
+#endif
     return (info == 0 && rel <= 1e-12) ? 0 : 2;
 }
