@@ -137,13 +137,16 @@ def other_configs(_capi, synthetic):
     out["ladybug1723"] = {"observations": len(p["obs_cam"]), "build_ms": ms_pass, "k_build_ms": ms_k,
                           "observations_per_sec": len(p["obs_cam"]) / (ms_pass * 1e-3),
                           "lm_iters_per_sec": max(s["iterations"], 1) / dt, "lm_pcg_iterations": s["pcg_iterations"]}
-    # NOT banded: 1778 cameras on a closed ring (loop closure), long tracks -> block-Jacobi PCG on the block-sparse S.
-    # Two settings of the inner tolerance: the library default (relative residual 1e-8: an "exact" Newton step, capped at
-    # pcg_max_iter) and an inexact-Newton forcing term of 0.1, which loses nothing in LM progress on this problem
+    # NOT banded: 1778 cameras on a closed ring (loop closure), long tracks.  Three ways: AUTO = block cyclic reduction
+    # (direct, the ring of camera blocks halved per level); block-Jacobi PCG on the block-sparse S at the library's
+    # default inner tolerance (relative residual 1e-8: an "exact" Newton step, capped at pcg_max_iter) and with an
+    # inexact-Newton forcing term of 0.1, which loses nothing in LM progress on this problem
     p = synthetic.make_config("ring1778_loop")
-    ring = {"cameras": len(p["cam_pose"]), "observations": len(p["obs_cam"]), "solver": "block-Jacobi PCG (pattern is not banded)"}
-    for tag, tol in (("pcg_tol_1e-8", 1e-8), ("pcg_tol_0.1", 0.1)):
-        with _capi.Handle(_capi.Arrays.from_dict(p), loss="huber", f_scale=1.0, max_iter=300, pcg_tol=tol) as h:
+    ring = {"cameras": len(p["cam_pose"]), "observations": len(p["obs_cam"]),
+            "solver": "auto = block cyclic reduction (a closed ring is not banded); the pcg_* entries force block-Jacobi PCG"}
+    for tag, kw in (("auto_cyclic_reduction", {}), ("pcg_tol_1e-8", dict(linear_solver="pcg", pcg_tol=1e-8)),
+                    ("pcg_tol_0.1", dict(linear_solver="pcg", pcg_tol=0.1))):
+        with _capi.Handle(_capi.Arrays.from_dict(p), loss="huber", f_scale=1.0, max_iter=300, **kw) as h:
             if "build_ms" not in ring:
                 h.build_bench(1e-4, warmup=0, reps=3)
                 ms_pass, ms_k = h.build_bench(1e-4, warmup=0, reps=10)

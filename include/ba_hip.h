@@ -163,6 +163,16 @@ int ba_eval_cost_noalloc(const BaProblem *prob, int32_t loss, double f_scale, do
 /* Host-only structure analysis (runs without a GPU). */
 int ba_analyze(const BaProblem *prob, BaAnalysis *out);
 
+/* Host-only (runs without a GPU): the block-cyclic-reduction schedule (csrc/ba_bcr.h) the engine would plan for a
+ * reduced-camera-system pattern of n_free cameras -- pairs: 2*n_pairs int32 free-camera indices (i <= j), the diagonal
+ * pairs included.  Serialised as int32 words into out (capacity words; *needed = words required, call with out = NULL
+ * to size it):  [ok, cyclic, m, nt, nb, n_slots, n_init_slots, levels] | blk_start[m+1] | src[(m+n_init_slots)*(nb/6)^2]
+ * | lvl_elim[levels+1] | lvl_op[levels+1] | elims[5 each: k, gu, gv, u, v] | ops[9 each: kind, dst, a0, b0, a1, b1, k0,
+ * k1, init].  ok = 0 (only the header is written): the pattern is neither a chain nor a ring of bandwidth <= 21 cameras.
+ * What the tests execute with NumPy to check the schedule against a dense solve.  (No reference counterpart: the
+ * reference leaves the linear algebra to scipy.) */
+int ba_bcr_plan(int32_t n_free, const int32_t *pairs, int64_t n_pairs, int32_t *out, int64_t capacity, int64_t *needed);
+
 /* ---- handle API: problem resident on the device across calls ------------------------ */
 BaHandle *ba_create(const BaProblem *prob, const BaOptions *opt);
 void ba_destroy(BaHandle *h);

@@ -26,6 +26,7 @@ EXPORTED = [
     "ba_get_state", "ba_get_cost", "ba_get_reduced_system", "ba_get_reduced_blocks", "ba_synchronize",
     "ba_set_values", "ba_set_collective_mode", "ba_get_stream", "ba_eval_cost_noalloc",
     "ba_eval_reprojection_errors_rt", "ba_get_reprojection_errors", "ba_rccl_unique_id", "ba_rccl_init", "ba_append",
+    "ba_bcr_plan",
 ]
 
 
@@ -100,6 +101,7 @@ def load():
     lib.ba_eval_reprojection_errors_rt.argtypes = [P(BaProblem), C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ba_get_reprojection_errors.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ba_rccl_unique_id.argtypes = [C.c_void_p]
+    lib.ba_bcr_plan.argtypes = [C.c_int32, P(C.c_int32), C.c_int64, P(C.c_int32), C.c_int64, P(C.c_int64)]
     lib.ba_rccl_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
     lib.ba_analyze.argtypes = [P(BaProblem), P(BaAnalysis)]
     lib.ba_create.argtypes = [P(BaProblem), P(BaOptions)]
@@ -131,6 +133,39 @@ def load():
 def check(code):
     if code != BA_OK:
         raise BaError(code, load().ba_last_error().decode("utf-8", "replace"))
+
+
+def bcr_plan(n_free, pairs):
+    """The block-cyclic-reduction schedule for a pattern (host only, no GPU): ``pairs`` = (n, 2) free-camera index pairs
+    of the upper blocks of S, diagonal included.  Returns None when the pattern has no schedule, else a dict of the
+    tables of ``csrc/ba_bcr.h`` (``src`` refers to the pairs in sorted unique order = the block order of S)."""
+    lib = load()
+    pr = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+    need = C.c_int64(0)
+    ptr = pr.ctypes.data_as(C.POINTER(C.c_int32))
+    check(lib.ba_bcr_plan(C.c_int32(n_free), ptr, C.c_int64(len(pr)), None, C.c_int64(0), C.byref(need)))
+    w = np.zeros(need.value, dtype=np.int32)
+    check(lib.ba_bcr_plan(C.c_int32(n_free), ptr, C.c_int64(len(pr)), w.ctypes.data_as(C.POINTER(C.c_int32)),
+                          C.c_int64(len(w)), C.byref(need)))
+    ok, cyclic, m, nt, nb, n_slots, n_init, levels = (int(v) for v in w[:8])
+    if not ok:
+        return None
+    at = [8]
+
+    def take(n):
+        out = w[at[0]:at[0] + n]
+        at[0] += n
+        return out
+    cbt = nb // 6
+    plan = dict(cyclic=bool(cyclic), m=m, nt=nt, nb=nb, n_slots=n_slots, n_init_slots=n_init, levels=levels)
+    plan["blk_start"] = take(m + 1)
+    plan["src"] = take((m + n_init) * cbt * cbt).reshape(m + n_init, cbt, cbt)
+    plan["lvl_elim"] = take(levels + 1)
+    plan["lvl_op"] = take(levels + 1)
+    plan["elims"] = take(5 * int(plan["lvl_elim"][-1])).reshape(-1, 5)
+    plan["ops"] = take(9 * int(plan["lvl_op"][-1])).reshape(-1, 9)
+    assert at[0] == len(w)
+    return plan
 
 
 def default_options(**kw):

@@ -1102,6 +1102,42 @@ int ba_append(BaHandle *h, const BaProblem *grown, const BaOptions *opt, int32_t
     }
 }
 
+int ba_bcr_plan(int32_t n_free, const int32_t *pairs, int64_t n_pairs, int32_t *out, int64_t capacity, int64_t *needed) {
+    if (!needed || n_pairs < 0 || (n_pairs > 0 && !pairs) || n_free < 0) return fail(BA_ERR_INVALID, "bad argument");
+    try {
+        std::vector<int64_t> keys;
+        keys.reserve((size_t)n_pairs);
+        for (int64_t i = 0; i < n_pairs; ++i) {
+            int a = pairs[2 * i], b = pairs[2 * i + 1];
+            if (a < 0 || b < 0 || a >= n_free || b >= n_free) return fail(BA_ERR_INVALID, "pattern pair out of range");
+            if (a > b) std::swap(a, b);
+            keys.push_back(((int64_t)a << 32) | (uint32_t)b);
+        }
+        std::sort(keys.begin(), keys.end());
+        keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+        BcrPlan P;
+        const bool ok = bcr_make_plan(n_free, keys.data(), keys.size(), P);
+        std::vector<int32_t> w = {ok ? 1 : 0, P.cyclic ? 1 : 0, P.m, P.nt, P.nb, P.n_slots, P.n_init_slots, ok ? P.levels() : 0};
+        if (ok) {
+            // src refers to the position of a pair in the SORTED UNIQUE list = the block order of S
+            w.insert(w.end(), P.blk_start.begin(), P.blk_start.end());
+            w.insert(w.end(), P.src.begin(), P.src.end());
+            w.insert(w.end(), P.lvl_elim.begin(), P.lvl_elim.end());
+            w.insert(w.end(), P.lvl_op.begin(), P.lvl_op.end());
+            for (const BcrElim &e : P.elims) w.insert(w.end(), {e.k, e.gu, e.gv, e.u, e.v});
+            for (const BcrOp &o : P.ops) w.insert(w.end(), {o.kind, o.dst, o.a0, o.b0, o.a1, o.b1, o.k0, o.k1, o.init});
+        }
+        *needed = (int64_t)w.size();
+        if (out) {
+            if (capacity < (int64_t)w.size()) return fail(BA_ERR_INVALID, "plan buffer too small");
+            std::copy(w.begin(), w.end(), out);
+        }
+        return BA_OK;
+    } catch (const std::bad_alloc &) {
+        return fail(BA_ERR_NOMEM, "out of host memory");
+    }
+}
+
 int ba_get_pattern(BaHandle *h, int32_t *out_pairs, int64_t capacity, int64_t *n_pairs) {
     if (!h || !n_pairs) return fail(BA_ERR_INVALID, "null argument");
     const auto &k = h->sym.upper_keys;

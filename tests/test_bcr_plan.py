@@ -1,0 +1,134 @@
+"""CPU: the block-cyclic-reduction schedule of ``csrc/ba_bcr.h`` (``ba_bcr_plan``, host only), EXECUTED with NumPy.
+
+The GPU kernels run whatever the planner's tables say -- which block is eliminated on which level, next to which
+neighbours, from which coupling slot, with which updates, and where every 6x6 block of S lands.  This test runs the same
+tables through plain NumPy linear algebra on random positive definite chain / ring systems and compares with a dense
+solve, so a wrong table shows up without a GPU: odd and even block counts, ragged last blocks, rings that shrink to
+three / four / five survivors, every block size (2, 4, 6, 8 tiles).  (The reference has no counterpart: it hands the
+whole least-squares problem to scipy, ``BundleAdjustment.py:210-220``.)
+"""
+import numpy as np
+import pytest
+
+from structure_from_motion_amd import _capi
+
+TRANSPOSED, SYMMETRISE, MASK = 1 << 30, 1 << 29, (1 << 29) - 1
+
+
+def _system(nf, band, ring, seed):
+    """Random SPD block system with the co-visibility of a chain (|i - j| <= band) or a closed ring."""
+    rng = np.random.default_rng(seed)
+    pairs = [(i, j) for i in range(nf) for j in range(i, nf) if j - i <= band or (ring and nf - (j - i) <= band)]
+    pairs = np.array(sorted(set(pairs)), dtype=np.int32)
+    blocks = rng.uniform(-1.0, 1.0, size=(len(pairs), 6, 6))
+    A = np.zeros((6 * nf, 6 * nf))
+    for k, (i, j) in enumerate(pairs):
+        if i == j:
+            blocks[k] = 0.5 * (blocks[k] + blocks[k].T) + (6.0 * (2 * band + 1) + 4.0) * np.eye(6)
+            A[6 * i:6 * i + 6, 6 * i:6 * i + 6] = blocks[k]
+        else:
+            A[6 * i:6 * i + 6, 6 * j:6 * j + 6] = blocks[k]
+            A[6 * j:6 * j + 6, 6 * i:6 * i + 6] = blocks[k].T
+    return pairs, blocks, A, rng.uniform(-1.0, 1.0, size=6 * nf)
+
+
+def _gather(plan, blocks):
+    """k_bcr_gather: every diagonal block / initial coupling slot from the src table."""
+    nb, cbt = plan["nb"], plan["nb"] // 6
+    out = np.zeros((len(plan["src"]), nb, nb))
+    for blk, table in enumerate(plan["src"]):
+        if blk < plan["m"]:
+            for o in range(6 * cbt, nb):
+                out[blk, o, o] = 1.0
+        for ro in range(cbt):
+            for co in range(cbt):
+                sc = int(table[ro, co])
+                if sc == -2:
+                    v = np.eye(6)
+                elif sc < 0:
+                    continue
+                else:
+                    b = blocks[sc & MASK]
+                    v = 0.5 * (b + b.T) if sc & SYMMETRISE else (b.T if sc & TRANSPOSED else b)
+                out[blk, 6 * ro:6 * ro + 6, 6 * co:6 * co + 6] = v
+    return out
+
+
+def _execute(plan, blocks, g):
+    m, nb = plan["m"], plan["nb"]
+    init = _gather(plan, blocks)
+    D = [np.tril(init[b]) + np.tril(init[b], -1).T for b in range(m)]          # the kernels read the lower triangle
+    G = {s: init[m + s].copy() for s in range(plan["n_init_slots"])}
+    bv = np.zeros((m, nb))
+    for b in range(m):
+        sz = 6 * (plan["blk_start"][b + 1] - plan["blk_start"][b])
+        bv[b, :sz] = -g[6 * plan["blk_start"][b]:6 * plan["blk_start"][b] + sz]
+    L = {}
+    for lv in range(plan["levels"]):
+        for k, gu, gv, u, v in plan["elims"][plan["lvl_elim"][lv]:plan["lvl_elim"][lv + 1]]:
+            L[k] = np.linalg.cholesky(D[k])
+            for slot in (gu, gv):
+                if slot >= 0:
+                    G[slot] = np.linalg.solve(L[k], G[slot].T).T                   # W = A(nb, k) L^-T
+            bv[k] = np.linalg.solve(L[k], bv[k])
+        for kind, dst, a0, b0, a1, b1, k0, k1, init_flag in plan["ops"][plan["lvl_op"][lv]:plan["lvl_op"][lv + 1]]:
+            if kind == 0:
+                for a, ky in ((a0, k0), (a1, k1)):
+                    if a >= 0:
+                        D[dst] = D[dst] - G[a] @ G[a].T
+                        bv[dst] = bv[dst] - G[a] @ bv[ky]
+            else:
+                acc = np.zeros((nb, nb)) if init_flag else G[dst].copy()
+                for a, b in ((a0, b0), (a1, b1)):
+                    if a >= 0:
+                        acc -= G[a] @ G[b].T
+                G[dst] = acc
+    x = np.zeros(len(g))
+    for lv in range(plan["levels"] - 1, -1, -1):
+        for k, gu, gv, u, v in plan["elims"][plan["lvl_elim"][lv]:plan["lvl_elim"][lv + 1]]:
+            r = bv[k].copy()
+            if gu >= 0:
+                r -= G[gu].T @ bv[u]
+            if gv >= 0:
+                r -= G[gv].T @ bv[v]
+            bv[k] = np.linalg.solve(L[k].T, r)
+            sz = 6 * (plan["blk_start"][k + 1] - plan["blk_start"][k])
+            x[6 * plan["blk_start"][k]:6 * plan["blk_start"][k] + sz] = bv[k][:sz]
+    return x
+
+
+CASES = [(12, 2, 0), (40, 3, 0), (41, 5, 0), (64, 5, 1), (37, 4, 1), (100, 8, 0), (90, 9, 1), (70, 15, 0), (113, 16, 0),
+         (48, 16, 1), (64, 16, 1), (83, 16, 1), (170, 17, 1), (420, 20, 1), (150, 21, 0), (33, 10, 1), (55, 10, 1), (7, 1, 0)]
+
+
+@pytest.mark.parametrize("nf,band,ring", CASES)
+def test_schedule_solves_the_system(nf, band, ring):
+    pairs, blocks, A, g = _system(nf, band, bool(ring), seed=nf * 100 + band)
+    plan = _capi.bcr_plan(nf, pairs)
+    assert plan is not None, "a chain / ring of this bandwidth has a schedule"
+    assert plan["cyclic"] == bool(ring) and plan["nb"] == 16 * plan["nt"] and plan["nt"] in (2, 4, 6, 8)
+    sizes = np.diff(plan["blk_start"])
+    assert plan["blk_start"][0] == 0 and plan["blk_start"][-1] == nf and sizes.min() >= 1 and 6 * sizes.max() <= plan["nb"]
+    if ring:
+        assert sizes.min() >= band and plan["m"] >= 3          # every block of a ring separates its neighbours
+    # every block is eliminated exactly once; the last level is the root alone
+    ks = plan["elims"][:, 0]
+    assert sorted(ks.tolist()) == list(range(plan["m"]))
+    assert plan["lvl_elim"][-1] - plan["lvl_elim"][-2] == 1 and tuple(plan["elims"][-1, 1:]) == (-1, -1, -1, -1)
+    assert plan["levels"] <= int(np.ceil(np.log2(plan["m"]))) + 1
+    x = _execute(plan, blocks, g)
+    want = np.linalg.solve(A, -g)
+    np.testing.assert_allclose(x, want, rtol=0, atol=1e-13 * max(1.0, np.abs(want).max()) * 10)
+
+
+def test_patterns_without_a_schedule():
+    nf = 60
+    dense = np.array([(i, j) for i in range(nf) for j in range(i, nf)], dtype=np.int32)
+    assert _capi.bcr_plan(nf, dense) is None                       # everybody sees everybody
+    wide = np.array([(i, j) for i in range(nf) for j in range(i, nf) if j - i <= 25], dtype=np.int32)
+    assert _capi.bcr_plan(nf, wide) is None                        # band beyond 21 cameras (8 tiles of 16 scalars)
+    chord = np.array([(i, i) for i in range(nf)] + [(i, i + 1) for i in range(nf - 1)] + [(10, 40)], dtype=np.int32)
+    assert _capi.bcr_plan(nf, chord) is None                       # a chain with one long-range pair
+    assert _capi.bcr_plan(1, np.array([(0, 0)], dtype=np.int32)) is None
+    with pytest.raises(_capi.BaError):
+        _capi.bcr_plan(4, np.array([(0, 7)], dtype=np.int32))       # index out of range
