@@ -825,11 +825,20 @@ struct BacksubArgs {
 
 __global__ __launch_bounds__(CHUNK_OBS) void k_backsub(const BacksubArgs A) {
     __shared__ double sP[CHUNK_PTS * 3];
-    __shared__ double sRed[4];
+    __shared__ double sRed[4][4];
     const int ck = blockIdx.x, tid = threadIdx.x;
     const int ob = A.ck_obs[ck], nobs = A.ck_obs[ck + 1] - ob;
     const int pb = A.ck_pt[ck], npts = A.ck_pt[ck + 1] - pb;
     for (int i = tid; i < npts * 3; i += CHUNK_OBS) sP[i] = 0.0;
+    // the per-point operands of the middle phase are requested now, not behind the barrier that precedes their use
+    double li[6] = {0, 0, 0, 0, 0, 0}, uu[3] = {0, 0, 0}, pp[3] = {0, 0, 0};
+    if (tid < npts) {
+        const size_t p = (size_t)(pb + tid);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) li[k] = A.pt_linv[p * 6 + k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { uu[k] = A.pt_u[p * 3 + k]; pp[k] = A.points[3 * p + k]; }
+    }
     __syncthreads();
     const bool act = tid < nobs;
     int lp = 0, cam = 0;
@@ -865,7 +874,6 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_backsub(const BacksubArgs A) {
     double dp2 = 0.0, xp2 = 0.0;
     if (tid < npts) {
         const size_t p = (size_t)(pb + tid);
-        const double *li = &A.pt_linv[p * 6], *uu = &A.pt_u[p * 3];
         const double i00 = li[0], i10 = li[1], i11 = li[2], i20 = li[3], i21 = li[4], i22 = li[5];
         const double s0 = sP[tid * 3], s1 = sP[tid * 3 + 1], s2 = sP[tid * 3 + 2];
         const double y0 = uu[0] + i00 * s0;
@@ -875,7 +883,7 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_backsub(const BacksubArgs A) {
         const double d1 = -(i11 * y1 + i21 * y2);
         const double d2 = -(i22 * y2);
         sP[tid * 3] = d0; sP[tid * 3 + 1] = d1; sP[tid * 3 + 2] = d2;
-        const double p0 = A.points[3 * p], p1 = A.points[3 * p + 1], p2 = A.points[3 * p + 2];
+        const double p0 = pp[0], p1 = pp[1], p2 = pp[2];
         A.points_t[3 * p] = p0 + d0; A.points_t[3 * p + 1] = p1 + d1; A.points_t[3 * p + 2] = p2 + d2;
         dp2 = d0 * d0 + d1 * d1 + d2 * d2;
         xp2 = p0 * p0 + p1 * p1 + p2 * p2;
@@ -895,14 +903,17 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_backsub(const BacksubArgs A) {
         loss_eval(A.loss, e1 * e1 * A.inv_fs2, rho1, wd);
         ft = A.half_fs2 * (rho0 + rho1);
     }
-    pred = block_sum256(pred, sRed);
-    ft = block_sum256(ft, sRed);
-    dp2 = block_sum256(dp2, sRed);
-    xp2 = block_sum256(xp2, sRed);
-    if (tid == 0) {
-        double *o = &A.ck_part[(size_t)ck * 4];
-        o[0] = pred; o[1] = ft; o[2] = dp2; o[3] = xp2;
+    // four block sums behind ONE barrier: DPP wave sums (fixed order), then the four wave results per quantity
+    pred = wave_sum_dpp(pred);
+    ft = wave_sum_dpp(ft);
+    dp2 = wave_sum_dpp(dp2);
+    xp2 = wave_sum_dpp(xp2);
+    if ((tid & 63) == 0) {
+        double *r = sRed[tid >> 6];
+        r[0] = pred; r[1] = ft; r[2] = dp2; r[3] = xp2;
     }
+    __syncthreads();
+    if (tid < 4) A.ck_part[(size_t)ck * 4 + tid] = (sRed[0][tid] + sRed[1][tid]) + (sRed[2][tid] + sRed[3][tid]);
 }
 
 // ------------------------------------------------------------------ deterministic reductions + LM control
