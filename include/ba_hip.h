@@ -166,7 +166,9 @@ int ba_analyze(const BaProblem *prob, BaAnalysis *out);
 /* Host-only (runs without a GPU): the block-cyclic-reduction schedule (csrc/ba_bcr.h) the engine would plan for a
  * reduced-camera-system pattern of n_free cameras -- pairs: 2*n_pairs int32 free-camera indices (i <= j), the diagonal
  * pairs included.  Serialised as int32 words into out (capacity words; *needed = words required, call with out = NULL
- * to size it):  [ok, cyclic, m, nt, nb, n_slots, n_init_slots, levels] | blk_start[m+1] | src[(m+n_init_slots)*(nb/6)^2]
+ * to size it):  [ok, cyclic | 2 * reordered, m, nt, nb, n_slots, n_init_slots, levels] | blk_start[m+1] | pos_f[m*(nb/6)]
+ * (free camera at (block, offset) or -1: the cameras are taken in index order, else in reverse Cuthill-McKee order) |
+ * src[(m+n_init_slots)*(nb/6)^2]
  * | lvl_elim[levels+1] | lvl_op[levels+1] | elims[5 each: k, gu, gv, u, v] | ops[9 each: kind, dst, a0, b0, a1, b1, k0,
  * k1, init].  ok = 0 (only the header is written): the pattern is neither a chain nor a ring of bandwidth <= 21 cameras.
  * What the tests execute with NumPy to check the schedule against a dense solve.  (No reference counterpart: the

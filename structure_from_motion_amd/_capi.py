@@ -157,8 +157,10 @@ def bcr_plan(n_free, pairs):
         at[0] += n
         return out
     cbt = nb // 6
-    plan = dict(cyclic=bool(cyclic), m=m, nt=nt, nb=nb, n_slots=n_slots, n_init_slots=n_init, levels=levels)
+    plan = dict(cyclic=bool(cyclic & 1), reordered=bool(cyclic & 2), m=m, nt=nt, nb=nb, n_slots=n_slots, n_init_slots=n_init,
+                levels=levels)
     plan["blk_start"] = take(m + 1)
+    plan["pos_f"] = take(m * cbt).reshape(m, cbt)
     plan["src"] = take((m + n_init) * cbt * cbt).reshape(m + n_init, cbt, cbt)
     plan["lvl_elim"] = take(levels + 1)
     plan["lvl_op"] = take(levels + 1)

@@ -31,7 +31,9 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <functional>
 #include <map>
+#include <queue>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -50,8 +52,10 @@ constexpr int32_t BCR_SRC_ZERO = -1, BCR_SRC_UNIT = -2;
 struct BcrPlan {
     bool ok = false, cyclic = false;
     int nf = 0, m = 0, nt = 0, nb = 0, band = 0, n_slots = 0, n_init_slots = 0;
-    std::vector<int32_t> blk_start;  // [m + 1] first free camera of each block
-    std::vector<int32_t> cam_blk;    // [nf] block << 8 | offset inside the block
+    bool reordered = false;          // the cameras are taken in reverse Cuthill-McKee order, not in index order
+    std::vector<int32_t> blk_start;  // [m + 1] first POSITION (in the elimination order of the cameras) of each block
+    std::vector<int32_t> pos_f;      // [m * (nb / 6)] free camera at (block, offset), -1 = padding
+    std::vector<int32_t> cam_blk;    // [nf] block << 8 | offset inside the block, per free camera
     std::vector<int32_t> edge_slot;  // [m] slot of the coupling between block b and b + 1 (entry m - 1: the ring's corner
                                      // block, between 0 and m - 1) | bit 30: rows belong to the higher block; -1: none
     std::vector<int32_t> src;        // [(m + n_init_slots) * cbt * cbt], cbt = nb / 6: per 6x6 block of the diagonal blocks and
@@ -62,15 +66,146 @@ struct BcrPlan {
     int levels() const { return (int)lvl_elim.size() - 1; }
 };
 
-// Plans the elimination for the pattern `keys` (sorted unique (i << 32 | j), i <= j, free-camera indices).  false: the
-// pattern is not a chain / ring with a half bandwidth of at most 21 cameras (or too small to bother).
-inline bool bcr_make_plan(int nf, const int64_t *keys, size_t nk, BcrPlan &P) {
+// Reverse Cuthill-McKee order of the camera graph (an edge per off-diagonal block of S): BFS from a pseudo-peripheral
+// camera, neighbours by increasing degree.  A chain whose cameras are NUMBERED in any other order than along the chain
+// (registration order of an incremental reconstruction, shuffled image lists) gets its small bandwidth back.
+inline void bcr_rcm_order(int nf, const int64_t *keys, size_t nk, std::vector<int32_t> &order) {
+    std::vector<int32_t> deg(nf + 1, 0);
+    for (size_t q = 0; q < nk; ++q) {
+        const int i = (int)(keys[q] >> 32), j = (int)(keys[q] & 0xffffffff);
+        if (i != j) { deg[i]++; deg[j]++; }
+    }
+    std::vector<int32_t> row(nf + 1, 0);
+    for (int c = 0; c < nf; ++c) row[c + 1] = row[c] + deg[c];
+    std::vector<int32_t> adj(row[nf]), fill(row.begin(), row.end() - 1);
+    for (size_t q = 0; q < nk; ++q) {
+        const int i = (int)(keys[q] >> 32), j = (int)(keys[q] & 0xffffffff);
+        if (i != j) { adj[fill[i]++] = j; adj[fill[j]++] = i; }
+    }
+    for (int c = 0; c < nf; ++c)
+        std::sort(adj.begin() + row[c], adj.begin() + row[c + 1], [&](int a, int b) { return deg[a] != deg[b] ? deg[a] < deg[b] : a < b; });
+    std::vector<int32_t> level(nf, -1), mark(nf, -1);
+    order.clear();
+    order.reserve(nf);
+    // breadth-first search from `root` inside the not yet ordered part; returns the last camera reached (smallest degree
+    // of the last level) and appends the visit order to `out`
+    auto bfs = [&](int root, int stamp, std::vector<int32_t> &out) {
+        const size_t first = out.size();
+        out.push_back(root);
+        mark[root] = stamp;
+        level[root] = 0;
+        for (size_t h = first; h < out.size(); ++h) {
+            const int c = out[h];
+            for (int e = row[c]; e < row[c + 1]; ++e) {
+                const int n = adj[e];
+                if (mark[n] == stamp || mark[n] == -2) continue;
+                mark[n] = stamp;
+                level[n] = level[c] + 1;
+                out.push_back(n);
+            }
+        }
+        int far = out.back();
+        for (size_t h = out.size(); h-- > first;) {
+            if (level[out[h]] != level[out.back()]) break;
+            if (deg[out[h]] < deg[far]) far = out[h];
+        }
+        return far;
+    };
+    int stamp = 0;
+    std::vector<int32_t> tmp;
+    for (int c0 = 0; c0 < nf; ++c0) {
+        if (mark[c0] == -2) continue;
+        int root = c0;
+        for (int rep = 0; rep < 3; ++rep) {   // pseudo-peripheral start: walk to the far end a few times
+            tmp.clear();
+            const int far = bfs(root, stamp++, tmp);
+            if (far == root) break;
+            root = far;
+        }
+        tmp.clear();
+        bfs(root, stamp++, tmp);
+        for (int c : tmp) { mark[c] = -2; order.push_back(c); }
+    }
+    std::reverse(order.begin(), order.end());
+}
+
+// Order along a chain whose co-visibility windows are irregular: every edge gets a LENGTH, the Jaccard distance of the
+// two cameras' neighbourhoods (cameras next to each other on the trajectory share nearly all their neighbours, cameras a
+// window apart share few), and the cameras are sorted by (distance from one end - distance from the other end) of the
+// weighted shortest paths.  Breadth-first levels (Cuthill-McKee) only resolve the position to a window width, which
+// doubles the bandwidth of such a chain; this coordinate resolves it inside the window.  Ends: the two ends of a
+// double sweep (farthest camera from camera 0, farthest from that).  One connected component only (else false).
+inline bool bcr_chain_order(int nf, const int64_t *keys, size_t nk, std::vector<int32_t> &order) {
+    std::vector<int32_t> row(nf + 1, 0);
+    for (size_t q = 0; q < nk; ++q) {
+        const int i = (int)(keys[q] >> 32), j = (int)(keys[q] & 0xffffffff);
+        if (i != j) { row[i + 1]++; row[j + 1]++; }
+    }
+    for (int c = 0; c < nf; ++c) row[c + 1] += row[c];
+    std::vector<int32_t> adj(row[nf]), fill(row.begin(), row.end() - 1);
+    for (size_t q = 0; q < nk; ++q) {
+        const int i = (int)(keys[q] >> 32), j = (int)(keys[q] & 0xffffffff);
+        if (i != j) { adj[fill[i]++] = j; adj[fill[j]++] = i; }
+    }
+    for (int c = 0; c < nf; ++c) std::sort(adj.begin() + row[c], adj.begin() + row[c + 1]);
+    std::vector<double> len(row[nf]);
+    for (int c = 0; c < nf; ++c)
+        for (int e = row[c]; e < row[c + 1]; ++e) {
+            const int n = adj[e];
+            int a = row[c], b = row[n], common = 2;   // (the two cameras themselves: closed neighbourhoods)
+            while (a < row[c + 1] && b < row[n + 1]) {
+                if (adj[a] == adj[b]) { ++common; ++a; ++b; }
+                else if (adj[a] < adj[b]) ++a;
+                else ++b;
+            }
+            const int uni = (row[c + 1] - row[c] + 1) + (row[n + 1] - row[n] + 1) - common;
+            len[e] = 1.0 - (double)common / (double)uni + 1e-3;
+        }
+    auto dijkstra = [&](int root, std::vector<double> &dist) {
+        dist.assign(nf, 1e300);
+        typedef std::pair<double, int> Item;
+        std::priority_queue<Item, std::vector<Item>, std::greater<Item>> pq;
+        dist[root] = 0.0;
+        pq.push(Item(0.0, root));
+        int far = root;
+        while (!pq.empty()) {
+            const Item it = pq.top();
+            pq.pop();
+            if (it.first > dist[it.second]) continue;
+            far = it.second;
+            for (int e = row[it.second]; e < row[it.second + 1]; ++e) {
+                const double d = it.first + len[e];
+                if (d < dist[adj[e]]) { dist[adj[e]] = d; pq.push(Item(d, adj[e])); }
+            }
+        }
+        return far;
+    };
+    std::vector<double> d0, d1, d2;
+    const int end1 = dijkstra(0, d0);
+    for (int c = 0; c < nf; ++c)
+        if (d0[c] >= 1e300) return false;   // not connected
+    const int end2 = dijkstra(end1, d1);
+    dijkstra(end2, d2);
+    order.resize(nf);
+    for (int c = 0; c < nf; ++c) order[c] = c;
+    std::sort(order.begin(), order.end(), [&](int a, int b) {
+        const double xa = d1[a] - d2[a], xb = d1[b] - d2[b];
+        return xa != xb ? xa < xb : a < b;
+    });
+    return true;
+}
+
+// Plans the elimination for the pattern `keys` (sorted unique (i << 32 | j), i <= j, free-camera indices) with the
+// cameras taken in the order `order`.
+inline bool bcr_plan_with_order(int nf, const int64_t *keys, size_t nk, const std::vector<int32_t> &order, BcrPlan &P) {
     P = BcrPlan{};
     if (nf < 2) return false;
+    std::vector<int32_t> pos(nf);
+    for (int k = 0; k < nf; ++k) pos[order[k]] = k;
     int near_b = 0, wrap_b = 0;
     for (size_t q = 0; q < nk; ++q) {
-        const int i = (int)(keys[q] >> 32), j = (int)(keys[q] & 0xffffffff), d = j - i;
-        if (d <= 0) continue;
+        const int i = (int)(keys[q] >> 32), j = (int)(keys[q] & 0xffffffff), d = std::abs(pos[j] - pos[i]);
+        if (d == 0) continue;
         if (2 * (int64_t)d <= nf) near_b = std::max(near_b, d);
         else wrap_b = std::max(wrap_b, nf - d);
     }
@@ -99,13 +234,18 @@ inline bool bcr_make_plan(int nf, const int64_t *keys, size_t nk, BcrPlan &P) {
     if (nt == 0 || m < 2) return false;
     P.nf = nf; P.m = m; P.nt = nt; P.nb = 16 * nt; P.band = band; P.cyclic = cyc;
     P.blk_start = start;
+    const int cbt = P.nb / 6;
     P.cam_blk.resize(nf);
+    P.pos_f.assign((size_t)m * cbt, -1);
     for (int b = 0; b < m; ++b)
-        for (int c = start[b]; c < start[b + 1]; ++c) P.cam_blk[c] = (b << 8) | (c - start[b]);
+        for (int k = start[b]; k < start[b + 1]; ++k) {
+            P.cam_blk[order[k]] = (b << 8) | (k - start[b]);
+            P.pos_f[(size_t)b * cbt + (k - start[b])] = order[k];
+        }
     for (size_t q = 0; q < nk; ++q) {
         const int i = (int)(keys[q] >> 32), j = (int)(keys[q] & 0xffffffff);
-        const int bi = P.cam_blk[i] >> 8, bj = P.cam_blk[j] >> 8;
-        if (!(bj == bi || bj == bi + 1 || (cyc && bi == 0 && bj == m - 1))) return false;
+        const int bi = P.cam_blk[i] >> 8, bj = P.cam_blk[j] >> 8, lo = std::min(bi, bj), hi = std::max(bi, bj);
+        if (!(hi == lo || hi == lo + 1 || (cyc && lo == 0 && hi == m - 1))) return false;
     }
     // pass 1: who is eliminated when, next to whom
     struct Lv { int k, u, v; };
@@ -197,22 +337,45 @@ inline bool bcr_make_plan(int nf, const int64_t *keys, size_t nk, BcrPlan &P) {
         P.lvl_op.push_back((int32_t)P.ops.size());
     }
     // where every 6x6 block of the diagonal blocks / initial coupling slots comes from
-    const int cbt = P.nb / 6;
     P.src.assign((size_t)(m + P.n_init_slots) * cbt * cbt, BCR_SRC_ZERO);
     for (int b = 0; b < m; ++b)   // padding cameras: unit diagonal
         for (int o = start[b + 1] - start[b]; o < cbt; ++o) P.src[((size_t)b * cbt + o) * cbt + o] = BCR_SRC_UNIT;
     for (size_t q = 0; q < nk; ++q) {
+        // S block q = A[camera i rows][camera j columns], i <= j
         const int i = (int)(keys[q] >> 32), j = (int)(keys[q] & 0xffffffff);
         const int bi = P.cam_blk[i] >> 8, oi = P.cam_blk[i] & 255, bj = P.cam_blk[j] >> 8, oj = P.cam_blk[j] & 255;
-        if (bi == bj) {   // lower triangle: row = camera j, column = camera i  ->  S_ij transposed
-            P.src[((size_t)bi * cbt + oj) * cbt + oi] = (int32_t)q | (i == j ? BCR_SRC_SYMMETRISE : BCR_SRC_TRANSPOSED);
-        } else {          // camera i sits in the lower-numbered block of the edge
-            const int es = P.edge_slot[bj == bi + 1 ? bi : m - 1], slot = es & 0x3fffffff;
-            if (es >> 30 & 1) P.src[((size_t)(m + slot) * cbt + oj) * cbt + oi] = (int32_t)q | BCR_SRC_TRANSPOSED;
-            else P.src[((size_t)(m + slot) * cbt + oi) * cbt + oj] = (int32_t)q;
+        if (i == j) {
+            P.src[((size_t)bi * cbt + oi) * cbt + oi] = (int32_t)q | BCR_SRC_SYMMETRISE;
+        } else if (bi == bj) {   // lower triangle of the diagonal block: the row is the camera further down the block
+            if (oj > oi) P.src[((size_t)bi * cbt + oj) * cbt + oi] = (int32_t)q | BCR_SRC_TRANSPOSED;
+            else P.src[((size_t)bi * cbt + oi) * cbt + oj] = (int32_t)q;
+        } else {
+            const int lo = std::min(bi, bj), hi = std::max(bi, bj);
+            const int es = P.edge_slot[hi == lo + 1 ? lo : m - 1], slot = es & 0x3fffffff;
+            const int rows = (es >> 30 & 1) ? hi : lo;   // the block whose cameras are the rows of the slot
+            if (bi == rows) P.src[((size_t)(m + slot) * cbt + oi) * cbt + oj] = (int32_t)q;
+            else P.src[((size_t)(m + slot) * cbt + oj) * cbt + oi] = (int32_t)q | BCR_SRC_TRANSPOSED;
         }
     }
     P.ok = true;
+    return true;
+}
+
+// Plans the elimination for the pattern `keys`: the cameras in index order first (chains and rings as the caller numbered
+// them), else along the chain coordinate of bcr_chain_order, else in reverse Cuthill-McKee order.  false: no order tried makes the pattern a chain / ring with a half
+// bandwidth of at most 21 cameras (or it is too small to bother).
+inline bool bcr_make_plan(int nf, const int64_t *keys, size_t nk, BcrPlan &P) {
+    if (nf < 2) { P = BcrPlan{}; return false; }
+    std::vector<int32_t> order(nf);
+    for (int c = 0; c < nf; ++c) order[c] = c;
+    if (bcr_plan_with_order(nf, keys, nk, order, P)) return true;
+    if (bcr_chain_order(nf, keys, nk, order) && bcr_plan_with_order(nf, keys, nk, order, P)) {
+        P.reordered = true;
+        return true;
+    }
+    bcr_rcm_order(nf, keys, nk, order);
+    if (!bcr_plan_with_order(nf, keys, nk, order, P)) return false;
+    P.reordered = true;
     return true;
 }
 
@@ -234,14 +397,15 @@ inline size_t bcr_factor_lds_bytes(int nt) {
 // flag.  (A memset of the blocks followed by a scatter of S took two fills and two kernels with their launch gaps: 60 us
 // in front of a 400 us solve.)
 __global__ void k_bcr_gather(int n_blocks, int m, int NB, const int32_t *__restrict__ src, const double *__restrict__ S,
-                             const int32_t *__restrict__ blk_start, const double *__restrict__ g, double *__restrict__ DG,
+                             const int32_t *__restrict__ pos_f, const double *__restrict__ g, double *__restrict__ DG,
                              double *__restrict__ bv, int *__restrict__ info) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t nb2 = (size_t)NB * NB;
     if (t == 0) *info = 0;
     if (t < (size_t)m * NB) {
-        const int b = (int)(t / NB), o = (int)(t - (size_t)b * NB), sz = 6 * (blk_start[b + 1] - blk_start[b]);
-        bv[t] = o < sz ? -g[(size_t)6 * blk_start[b] + o] : 0.0;
+        const int b = (int)(t / NB), o = (int)(t - (size_t)b * NB), cb = NB / 6;
+        const int f = o < 6 * cb ? pos_f[b * cb + o / 6] : -1;
+        bv[t] = f >= 0 ? -g[(size_t)6 * f + o % 6] : 0.0;
     }
     if (t >= (size_t)n_blocks * nb2) return;
     const int blk = (int)(t / nb2), e = (int)(t - blk * nb2), r = e / NB, c = e - r * NB;
@@ -566,7 +730,7 @@ __global__ __launch_bounds__(256) void k_bcr_update(int n_ops, const BcrOp *__re
 template <int NT>
 __global__ __launch_bounds__(512) void k_bcr_back(const BcrElim *__restrict__ elims, const double *__restrict__ D,
                                                   const double *__restrict__ G, double *__restrict__ bv,
-                                                  const double *__restrict__ Linv16, const int32_t *__restrict__ blk_start,
+                                                  const double *__restrict__ Linv16, const int32_t *__restrict__ pos_f,
                                                   double *__restrict__ xout) {
     constexpr int NB = 16 * NT, PARTS = 512 / NB, RP = (NB + PARTS - 1) / PARTS;
     extern __shared__ double bcr_smem[];
@@ -580,7 +744,7 @@ __global__ __launch_bounds__(512) void k_bcr_back(const BcrElim *__restrict__ el
     const size_t nb2 = (size_t)NB * NB;
     // (every trip to memory starts here, not behind a barrier)
     const double yk = tid < NB ? bv[(size_t)el.k * NB + tid] : 0.0;
-    const int c0 = blk_start[el.k], sz = 6 * (blk_start[el.k + 1] - c0);
+    const int fcam = tid < 6 * (NB / 6) ? pos_f[el.k * (NB / 6) + tid / 6] : -1;   // the camera of unknown tid of this block
     {
         const double *L = D + el.k * nb2, *li = Linv16 + (size_t)el.k * NT * 256;
         for (int e = tid; e < NB * NB; e += 512) sL[e] = L[e];
@@ -638,7 +802,7 @@ __global__ __launch_bounds__(512) void k_bcr_back(const BcrElim *__restrict__ el
     }
     if (tid < NB) {
         bv[(size_t)el.k * NB + tid] = srhs[tid];
-        if (tid < sz) xout[(size_t)6 * c0 + tid] = srhs[tid];
+        if (fcam >= 0) xout[(size_t)6 * fcam + tid % 6] = srhs[tid];
     }
 }
 
@@ -646,7 +810,7 @@ __global__ __launch_bounds__(512) void k_bcr_back(const BcrElim *__restrict__ el
 struct BcrDev {
     const BcrElim *elims;
     const BcrOp *ops;
-    const int32_t *src, *blk_start;
+    const int32_t *src, *pos_f;
     double *DG;      // bcr_matrix_doubles: m diagonal blocks, then the coupling slots
     double *bv;      // bcr_vec_doubles
     double *linv;    // bcr_linv_doubles
@@ -678,7 +842,7 @@ inline hipError_t bcr_solve_launch_t(hipStream_t st, const BcrPlan &P, const Bcr
     {
         const int n_blocks = P.m + P.n_init_slots;
         const size_t n_el = (size_t)n_blocks * nb2;
-        hipLaunchKernelGGL(k_bcr_gather, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, st, n_blocks, P.m, NB, d.src, S, d.blk_start, g,
+        hipLaunchKernelGGL(k_bcr_gather, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, st, n_blocks, P.m, NB, d.src, S, d.pos_f, g,
                            d.DG, d.bv, d.info);
     }
     const size_t lds = bcr_factor_lds_bytes(NT);
@@ -693,7 +857,7 @@ inline hipError_t bcr_solve_launch_t(hipStream_t st, const BcrPlan &P, const Bcr
     }
     for (int l = nl - 1; l >= 0; --l) {
         const int ne_l = P.lvl_elim[l + 1] - P.lvl_elim[l];
-        hipLaunchKernelGGL(k_bcr_back<NT>, dim3(ne_l), dim3(512), bcr_back_lds_bytes(NT), st, d.elims + P.lvl_elim[l], D, G, d.bv, d.linv, d.blk_start, x);
+        hipLaunchKernelGGL(k_bcr_back<NT>, dim3(ne_l), dim3(512), bcr_back_lds_bytes(NT), st, d.elims + P.lvl_elim[l], D, G, d.bv, d.linv, d.pos_f, x);
     }
     return hipGetLastError();
 }

@@ -553,7 +553,7 @@ int bcr_plan_for(BaHandle *h) {
     h->bcr_off[0] = put(P.elims.data(), P.elims.size() * sizeof(BcrElim) / 4);
     h->bcr_off[1] = put(P.ops.data(), P.ops.size() * sizeof(BcrOp) / 4);
     h->bcr_off[2] = put(P.src.data(), P.src.size());
-    h->bcr_off[3] = put(P.blk_start.data(), P.blk_start.size());
+    h->bcr_off[3] = put(P.pos_f.data(), P.pos_f.size());
     HIPCHK(h->bcr_tab.upload(tab, h->stream));
     HIPCHK(h->bcr_dg.alloc(bcr_matrix_doubles(P)));
     HIPCHK(h->bcr_bv.alloc(bcr_vec_doubles(P)));
@@ -572,7 +572,7 @@ int do_bcr(BaHandle *h, bool *launched) {
     d.elims = reinterpret_cast<const BcrElim *>(t + h->bcr_off[0]);
     d.ops = reinterpret_cast<const BcrOp *>(t + h->bcr_off[1]);
     d.src = t + h->bcr_off[2];
-    d.blk_start = t + h->bcr_off[3];
+    d.pos_f = t + h->bcr_off[3];
     d.DG = h->bcr_dg.p; d.bv = h->bcr_bv.p; d.linv = h->bcr_linv.p; d.info = h->dense_info.p;
     HIPCHK(bcr_solve_launch(h->stream, h->bcr_plan, d, h->S, h->gred, h->px.p));
     return BA_OK;  // (pivot flag: see do_step)
@@ -1117,10 +1117,11 @@ int ba_bcr_plan(int32_t n_free, const int32_t *pairs, int64_t n_pairs, int32_t *
         keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
         BcrPlan P;
         const bool ok = bcr_make_plan(n_free, keys.data(), keys.size(), P);
-        std::vector<int32_t> w = {ok ? 1 : 0, P.cyclic ? 1 : 0, P.m, P.nt, P.nb, P.n_slots, P.n_init_slots, ok ? P.levels() : 0};
+        std::vector<int32_t> w = {ok ? 1 : 0, (P.cyclic ? 1 : 0) | (P.reordered ? 2 : 0), P.m, P.nt, P.nb, P.n_slots, P.n_init_slots, ok ? P.levels() : 0};
         if (ok) {
             // src refers to the position of a pair in the SORTED UNIQUE list = the block order of S
             w.insert(w.end(), P.blk_start.begin(), P.blk_start.end());
+            w.insert(w.end(), P.pos_f.begin(), P.pos_f.end());
             w.insert(w.end(), P.src.begin(), P.src.end());
             w.insert(w.end(), P.lvl_elim.begin(), P.lvl_elim.end());
             w.insert(w.end(), P.lvl_op.begin(), P.lvl_op.end());

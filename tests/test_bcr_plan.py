@@ -15,10 +15,13 @@ from structure_from_motion_amd import _capi
 TRANSPOSED, SYMMETRISE, MASK = 1 << 30, 1 << 29, (1 << 29) - 1
 
 
-def _system(nf, band, ring, seed):
-    """Random SPD block system with the co-visibility of a chain (|i - j| <= band) or a closed ring."""
+def _system(nf, band, ring, seed, shuffle=False):
+    """Random SPD block system with the co-visibility of a chain (|i - j| <= band) or a closed ring; ``shuffle``: the
+    cameras are numbered at random (the chain is still there, in another order)."""
     rng = np.random.default_rng(seed)
-    pairs = [(i, j) for i in range(nf) for j in range(i, nf) if j - i <= band or (ring and nf - (j - i) <= band)]
+    name = rng.permutation(nf) if shuffle else np.arange(nf)
+    pairs = [(min(name[i], name[j]), max(name[i], name[j])) for i in range(nf) for j in range(i, nf)
+             if j - i <= band or (ring and nf - (j - i) <= band)]
     pairs = np.array(sorted(set(pairs)), dtype=np.int32)
     blocks = rng.uniform(-1.0, 1.0, size=(len(pairs), 6, 6))
     A = np.zeros((6 * nf, 6 * nf))
@@ -61,8 +64,9 @@ def _execute(plan, blocks, g):
     G = {s: init[m + s].copy() for s in range(plan["n_init_slots"])}
     bv = np.zeros((m, nb))
     for b in range(m):
-        sz = 6 * (plan["blk_start"][b + 1] - plan["blk_start"][b])
-        bv[b, :sz] = -g[6 * plan["blk_start"][b]:6 * plan["blk_start"][b] + sz]
+        for o, f in enumerate(plan["pos_f"][b]):
+            if f >= 0:
+                bv[b, 6 * o:6 * o + 6] = -g[6 * f:6 * f + 6]
     L = {}
     for lv in range(plan["levels"]):
         for k, gu, gv, u, v in plan["elims"][plan["lvl_elim"][lv]:plan["lvl_elim"][lv + 1]]:
@@ -92,8 +96,9 @@ def _execute(plan, blocks, g):
             if gv >= 0:
                 r -= G[gv].T @ bv[v]
             bv[k] = np.linalg.solve(L[k].T, r)
-            sz = 6 * (plan["blk_start"][k + 1] - plan["blk_start"][k])
-            x[6 * plan["blk_start"][k]:6 * plan["blk_start"][k] + sz] = bv[k][:sz]
+            for o, f in enumerate(plan["pos_f"][k]):
+                if f >= 0:
+                    x[6 * f:6 * f + 6] = bv[k][6 * o:6 * o + 6]
     return x
 
 
@@ -107,6 +112,8 @@ def test_schedule_solves_the_system(nf, band, ring):
     plan = _capi.bcr_plan(nf, pairs)
     assert plan is not None, "a chain / ring of this bandwidth has a schedule"
     assert plan["cyclic"] == bool(ring) and plan["nb"] == 16 * plan["nt"] and plan["nt"] in (2, 4, 6, 8)
+    assert not plan["reordered"]
+    assert sorted(plan["pos_f"][plan["pos_f"] >= 0].tolist()) == list(range(nf))
     sizes = np.diff(plan["blk_start"])
     assert plan["blk_start"][0] == 0 and plan["blk_start"][-1] == nf and sizes.min() >= 1 and 6 * sizes.max() <= plan["nb"]
     if ring:
@@ -121,14 +128,49 @@ def test_schedule_solves_the_system(nf, band, ring):
     np.testing.assert_allclose(x, want, rtol=0, atol=1e-13 * max(1.0, np.abs(want).max()) * 10)
 
 
+@pytest.mark.parametrize("nf,band", [(60, 3), (150, 7), (200, 10), (97, 2)])
+def test_shuffled_camera_numbering_is_reordered(nf, band):
+    """The chain is there but the cameras are numbered at random (registration order of an incremental reconstruction):
+    in index order the pattern has no bandwidth, reverse Cuthill-McKee finds the chain again."""
+    pairs, blocks, A, g = _system(nf, band, False, seed=nf + band, shuffle=True)
+    plan = _capi.bcr_plan(nf, pairs)
+    assert plan is not None and plan["reordered"] and not plan["cyclic"]
+    assert sorted(plan["pos_f"][plan["pos_f"] >= 0].tolist()) == list(range(nf))
+    x = _execute(plan, blocks, g)
+    want = np.linalg.solve(A, -g)
+    np.testing.assert_allclose(x, want, rtol=0, atol=1e-12 * max(1.0, np.abs(want).max()))
+
+
+def test_loop_closure_inside_a_chain():
+    """A chain with one long-range pair (cameras 10 and 40 see the same landmarks: a revisit) has no bandwidth in index
+    order; reordered, the loop 10..40 folds onto itself and the bandwidth doubles at most."""
+    nf = 60
+    rng = np.random.default_rng(4)
+    pairs = np.array(sorted([(i, i) for i in range(nf)] + [(i, i + 1) for i in range(nf - 1)] + [(i, i + 2) for i in range(nf - 2)]
+                            + [(10, 40), (10, 41), (11, 40)]), dtype=np.int32)
+    blocks = rng.uniform(-1.0, 1.0, size=(len(pairs), 6, 6))
+    A = np.zeros((6 * nf, 6 * nf))
+    for k, (i, j) in enumerate(pairs):
+        if i == j:
+            blocks[k] = 0.5 * (blocks[k] + blocks[k].T) + 40.0 * np.eye(6)
+            A[6 * i:6 * i + 6, 6 * i:6 * i + 6] = blocks[k]
+        else:
+            A[6 * i:6 * i + 6, 6 * j:6 * j + 6] = blocks[k]
+            A[6 * j:6 * j + 6, 6 * i:6 * i + 6] = blocks[k].T
+    g = rng.uniform(-1.0, 1.0, size=6 * nf)
+    plan = _capi.bcr_plan(nf, pairs)
+    assert plan is not None and plan["reordered"]
+    np.testing.assert_allclose(_execute(plan, blocks, g), np.linalg.solve(A, -g), rtol=0, atol=1e-12)
+
+
 def test_patterns_without_a_schedule():
     nf = 60
     dense = np.array([(i, j) for i in range(nf) for j in range(i, nf)], dtype=np.int32)
     assert _capi.bcr_plan(nf, dense) is None                       # everybody sees everybody
     wide = np.array([(i, j) for i in range(nf) for j in range(i, nf) if j - i <= 25], dtype=np.int32)
     assert _capi.bcr_plan(nf, wide) is None                        # band beyond 21 cameras (8 tiles of 16 scalars)
-    chord = np.array([(i, i) for i in range(nf)] + [(i, i + 1) for i in range(nf - 1)] + [(10, 40)], dtype=np.int32)
-    assert _capi.bcr_plan(nf, chord) is None                       # a chain with one long-range pair
+    star = np.array([(i, i) for i in range(nf)] + [(0, i) for i in range(1, nf)], dtype=np.int32)
+    assert _capi.bcr_plan(nf, star) is None                        # one camera sees what every other sees: no order helps
     assert _capi.bcr_plan(1, np.array([(0, 0)], dtype=np.int32)) is None
     with pytest.raises(_capi.BaError):
         _capi.bcr_plan(4, np.array([(0, 7)], dtype=np.int32))       # index out of range

@@ -354,12 +354,47 @@ def test_cyclic_reduction_on_a_closed_ring(gpu):
     np.testing.assert_allclose(out["auto"][1].cam_pose, out["pcg"][1].cam_pose, rtol=1e-4, atol=1e-5)
 
 
+def _renumber_cameras(p, seed):
+    """The same problem with its cameras numbered at random."""
+    rng = np.random.default_rng(seed)
+    nc = len(p["cam_pose"])
+    new_of_old = rng.permutation(nc)
+    old_of_new = np.argsort(new_of_old)
+    q = dict(p)
+    for k in ("cam_pose", "cam_intr", "cam_fixed"):
+        q[k] = np.ascontiguousarray(p[k][old_of_new])
+    q["obs_cam"] = new_of_old[p["obs_cam"]].astype(np.int32)
+    return q, new_of_old
+
+
+def test_cyclic_reduction_does_not_depend_on_the_camera_numbering(gpu):
+    """An incremental reconstruction numbers its cameras in registration order, not along the trajectory.  The planner
+    falls back to a reverse Cuthill-McKee order of the camera graph: a street chain with shuffled numbering and a closed
+    ring with shuffled numbering (folded onto itself: twice the bandwidth) are still solved directly, on the same LM path
+    as the problem in its natural numbering."""
+    for p, solver, max_iter in ((synthetic.make_street(203, 5000, 22000, seed=51, outlier_frac=0.01), "auto", 15),
+                                (synthetic.make_ring(120, 6000, seed=71, mean_track=5.0, max_track=9, n_fixed=2, outlier_frac=0.01),
+                                 "cyclic_reduction", 15)):
+        q, new_of_old = _renumber_cameras(p, 5)
+        ap, aq = _capi.Arrays.from_dict(p), _capi.Arrays.from_dict(q)
+        sp = _capi.solve(ap, loss="huber", f_scale=1.0, max_iter=max_iter, linear_solver=solver)
+        sq = _capi.solve(aq, loss="huber", f_scale=1.0, max_iter=max_iter, linear_solver=solver)
+        assert sp["pcg_iterations"] == 0 and sq["pcg_iterations"] == 0            # both direct
+        assert sq["iterations"] == sp["iterations"] and sq["accepted"] == sp["accepted"] and sp["accepted"] >= 3
+        assert abs(sq["final_cost"] - sp["final_cost"]) <= 1e-9 * sp["final_cost"]
+        np.testing.assert_allclose(aq.cam_pose[new_of_old], ap.cam_pose, rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(aq.points, ap.points, rtol=1e-6, atol=1e-7)
+
+
 def test_cyclic_reduction_requested_on_a_pattern_without_a_schedule(gpu, monkeypatch):
     """Landmarks seen by every camera make S full: no chain / ring schedule, the request falls through to PCG.  And a
     bad pivot inside the cyclic reduction voids the step like in the other direct solvers."""
     p = synthetic.make_ring(40, 1500, seed=73, mean_track=4.0, n_fixed=2, n_landmarks=20)
     out = _lm_paths(p, ("cyclic_reduction", "pcg"), 10, pcg_tol=1e-10)
-    assert out["cyclic_reduction"][0]["pcg_iterations"] == out["pcg"][0]["pcg_iterations"] > 0
+    # (the same PCG path twice: the fp64 atomics of the build make two runs differ in the last bits, and with them the
+    # iteration count by one or two)
+    n_req, n_pcg = out["cyclic_reduction"][0]["pcg_iterations"], out["pcg"][0]["pcg_iterations"]
+    assert n_pcg > 0 and abs(n_req - n_pcg) <= 0.02 * n_pcg + 2
     assert out["cyclic_reduction"][0]["final_cost"] == pytest.approx(out["pcg"][0]["final_cost"], rel=1e-9)
     p = synthetic.make_street(30, 800, 3500, seed=33, outlier_frac=0.02)
     a1, a2 = _capi.Arrays.from_dict(p), _capi.Arrays.from_dict(p)
