@@ -611,7 +611,7 @@ int step_tail(BaHandle *h, const int *solve_info) {
     hipLaunchKernelGGL(k_add_scalar, dim3(1), dim3(1), 0, st, h->step_sums.p + 3, h->x2_const);
     if (h->coll && (e = call_coll(h, h->step_sums.p, 4, BA_REDUCE_SUM))) return e;
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(1), 0, st, h->state.p, h->step_sums.p, h->cam_sums.p, 0.0,
-                       h->opt.ftol, h->opt.xtol, solve_info);
+                       h->opt.ftol, h->opt.xtol, h->opt.gtol, solve_info);
     HIPCHK(hipGetLastError());
     return BA_OK;
 }
@@ -1299,14 +1299,23 @@ int ba_run(BaHandle *h, int32_t max_steps, BaSummary *out) {
     // (sharded solve: the point count is this rank's, and a rank that left the loop alone would leave its peers in a
     // collective; there gmax -- all-reduced -- ends an empty problem on every rank at once)
     const int n_unknown = h->coll ? 1 : h->sym.n_free * 6 + h->sym.n_pts_obs * 3;
+    // One host round trip per step (the accept / reject decision, which selects the state buffers of the next launches).
+    // The state is NOT read back after the build that follows: the gradient test of that build is made on the device by
+    // the next step's k_decide (terminate = 1, step void), the host's copy of F / gmax is refreshed at the end.
+    bool fresh = true;   // hstate holds the outcome of the latest build
     for (int step = 0; step < max_steps; ++step) {
-        if (h->hstate.gmax < h->opt.gtol || n_unknown == 0) {
+        if ((fresh && h->hstate.gmax < h->opt.gtol) || n_unknown == 0) {
             status = 1;
             break;
         }
         const int pcg_before = h->total_pcg;
         if ((e = do_step(h))) return e;
         const LmState &s = h->hstate;
+        if (s.terminate == 1 && !s.accept && s.solve_info == 0) {   // the build before this step had already converged (gtol)
+            status = 1;
+            fresh = true;   // (nothing was built since the state was read)
+            break;
+        }
         if (verbose >= 2)
             printf("%12d %12d %16.4e %16.2e %14.2e %14.2e %11.1e %5d %s\n", s.iter, s.iter + 1, s.F, s.accept ? s.dF : 0.0,
                    s.step_norm, s.gmax, s.lambda, h->total_pcg - pcg_before, s.accept ? "" : "(rejected)");
@@ -1315,11 +1324,13 @@ int ba_run(BaHandle *h, int32_t max_steps, BaSummary *out) {
             // the last build belongs to the pre-step state: refresh F / gradient if the step was taken
             if (s.accept && (e = do_build(h, false))) return e;
             if (s.accept && (e = read_state(h))) return e;
+            fresh = true;
             break;
         }
         if ((e = do_build(h, false))) return e;  // new linearisation (accepted) or new damping (rejected)
-        if ((e = read_state(h))) return e;
+        fresh = false;
     }
+    if (!fresh && (e = read_state(h))) return e;
     fill_summary(h, out, status, now_ms() - t0);
     if (out) {
         double c, rs;

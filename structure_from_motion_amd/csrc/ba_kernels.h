@@ -1073,7 +1073,16 @@ __global__ __launch_bounds__(256) void k_state_after_build(LmState *st, const do
 // solve_info (may be null): != 0 when the direct solver met a non-positive pivot -- the step is void, the state stays
 // as it is and the host repeats the step with PCG
 __global__ void k_decide(LmState *st, const double *step, const double *cams, double x2_const, double ftol, double xtol,
-                         const int *solve_info) {
+                         double gtol, const int *solve_info) {
+    // scipy's gtol test on the gradient of the linearisation this step started from.  It sits here, not on the host, so
+    // that the host does not have to read the state back after every build: a step queued behind a build whose gradient
+    // was already small is void (state untouched), terminate = 1 tells the host.
+    if (st->gmax < gtol) {
+        st->solve_info = 0;
+        st->accept = 0;
+        st->terminate = 1;
+        return;
+    }
     st->solve_info = solve_info ? *solve_info : 0;
     if (st->solve_info != 0) return;
     const double pred = step[0], Ft = step[1];
