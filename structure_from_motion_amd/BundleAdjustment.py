@@ -13,6 +13,9 @@ There is no CPU fallback: without ``libba_hip.so`` and a GPU the solve raises in
 ``try`` below and -- exactly like any other failure in the reference (``:238-240``) -- is
 reported as ``[BA] Bundle adjustment error: ...`` with ``(cameras, points_3d, False)``.
 """
+import itertools
+import operator
+
 import numpy as np
 
 from . import _capi
@@ -173,12 +176,35 @@ def _track_arrays(cam_data, n_points):
     return a[:, 0], a[:, 1]
 
 
+_PT = operator.attrgetter("pt")
+
+
+def _keypoint_xy(kp, kidx):
+    """(len(kidx), 2) float64 pixel coordinates ``kp[k].pt`` (:269).  One flat iterator into ``np.fromiter``: less than
+    half the time of ``np.array`` over a list of tuples, and the keypoints are most of what a ``final_ba`` call reads."""
+    flat = itertools.chain.from_iterable(map(_PT, map(kp.__getitem__, kidx.tolist())))
+    return np.fromiter(flat, dtype=np.float64, count=2 * len(kidx)).reshape(-1, 2)
+
+
+def _rows_to_array(rows):
+    """``np.asarray(rows, float64)`` for the driver's list of equally long point rows ([x, y, z, r, g, b] lists,
+    ``Reconstruction.py:41-47``), through a flat iterator (about half the time); anything else goes to ``np.asarray``."""
+    if isinstance(rows, list) and rows and isinstance(rows[0], (list, tuple)):
+        w = len(rows[0])
+        if w and set(map(len, rows)) == {w}:
+            try:
+                return np.fromiter(itertools.chain.from_iterable(rows), dtype=np.float64, count=w * len(rows)).reshape(-1, w)
+            except (TypeError, ValueError):
+                pass
+    return np.asarray(rows, dtype=np.float64)
+
+
 def _image_data_to_arrays(image_data, all_points_3D, visited_ids, keypoints=None):
     """The driver's containers -> (Arrays without gauge, cam_ids, colours (Np, 3) or None), with NumPy instead of one
     Python object per observation.  Same camera order, observation order and validity rules as
     ``prepare_cameras_from_image_data`` + ``prepare_observations_from_image_data`` + ``_to_arrays`` (the tests compare
     them array by array).  ``keypoints(img_id, kp) -> (k, 2) float64`` lets a caller cache the pixel coordinates."""
-    pts6 = np.asarray(all_points_3D, dtype=np.float64)
+    pts6 = _rows_to_array(all_points_3D)
     if pts6.ndim != 2 or pts6.shape[1] < 3:
         pts6 = np.array([[p[0], p[1], p[2]] for p in all_points_3D], dtype=np.float64).reshape(-1, 3)
     points = np.ascontiguousarray(pts6[:, :3])
@@ -204,7 +230,7 @@ def _image_data_to_arrays(image_data, all_points_3D, visited_ids, keypoints=None
             xy = keypoints(img_id, kp) if keypoints is not None else None
             oc.append(np.full(len(kidx), index_of[img_id], dtype=np.int32))
             op.append(pidx.astype(np.int32))
-            oxy.append(xy[kidx] if xy is not None else np.array([kp[k].pt for k in kidx], dtype=np.float64).reshape(-1, 2))
+            oxy.append(xy[kidx] if xy is not None else _keypoint_xy(kp, kidx))
     obs_cam = np.concatenate(oc) if oc else np.zeros(0, np.int32)
     obs_pt = np.concatenate(op) if op else np.zeros(0, np.int32)
     obs_xy = np.concatenate(oxy) if oxy else np.zeros((0, 2))
