@@ -164,6 +164,62 @@ def other_configs(_capi, synthetic):
     return out
 
 
+def pmc_child(args):
+    """What the PMC passes of live_traffic() profile: the workload, a handle, a few build passes.  No torch."""
+    from structure_from_motion_amd import _capi, synthetic
+    nc, n_pts, n_obs = synthetic.SHAPES[args.workload]
+    n_pts, n_obs = max(int(n_pts * args.scale), 64), max(int(n_obs * args.scale), 256)
+    idx = {"ladybug1723": 3, "venice1778": 4, "city10k": 5}[args.workload]
+    prob = synthetic.make_street(nc, n_pts, n_obs, seed=1233 + idx)
+    with _capi.Handle(_capi.Arrays.from_dict(prob), loss="huber", f_scale=1.0, max_iter=300) as h:
+        h.build_bench(1e-4, warmup=1, reps=5)
+
+
+def live_traffic(args):
+    """HBM bytes per k_build launch, measured NOW: two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one
+    pass) over a child process that runs this file with --pmc-child, counters read and corrected as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes (both in KiB per dispatch; gfx950 tallies the 128-byte requests of
+    wide coalesced reads at 64 bytes: 2 x FETCH_SIZE, an upper bound for this kernel's narrow gathers; WRITE_SIZE is
+    exact for float atomics).  Returns (bytes, detail) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    got = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        with tempfile.TemporaryDirectory(dir="/tmp") as d:
+            cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
+                   os.path.abspath(__file__), "--pmc-child", "--workload", args.workload, "--scale", str(args.scale)]
+            env = dict(os.environ, TMPDIR="/tmp")
+            try:
+                pr = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+                try:
+                    pr.wait(timeout=180)
+                except subprocess.TimeoutExpired:
+                    os.killpg(pr.pid, signal.SIGKILL)      # the process group started here, nothing else
+                    pr.wait()
+                    return None, f"{counter} pass timed out"
+            except OSError as e:
+                return None, f"rocprofv3 did not start: {e}"
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for r in csv.DictReader(fh):
+                        if "k_build" in r["Kernel_Name"] and "heavy" not in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                            vals.append(float(r["Counter_Value"]))
+            if not vals:
+                return None, f"{counter} pass left no k_build rows (exit code {pr.returncode})"
+            got[counter] = sum(vals) / len(vals) * 1024.0
+    return 2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"], {
+        "source": "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this run's workload (separate passes)",
+        "fetch_bytes_2x": 2.0 * got["FETCH_SIZE"], "write_bytes": got["WRITE_SIZE"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -177,7 +233,11 @@ def main():
     ap.add_argument("--cpu-sample-obs", type=int, default=150000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true", help="take roofline.traffic from profiles/traffic.json instead of measuring it")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.pmc_child:
+        return pmc_child(args)
 
     import torch
     import torch.distributed as dist
@@ -265,6 +325,7 @@ def main():
         traffic = json.load(open(tf)).get(f"{args.workload}@{args.scale:g}")
     roofline = {"bound": "hbm", "kernel": "k_build", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_detail": {"source": "profiles/traffic.json (recorded PMC passes)"} if traffic is not None else None,
                 "algorithmic_bytes_per_launch": alg, "kernel_ms": ms_kernel}
     # the kernel sits near the ridge: the fp64 VALU ceiling next to the HBM one.  Algorithmic flops:
     # 430 per observation (projection, analytic blocks, U/V/W/g) + 108 + 108 (L + 1) per observation for the explicit
@@ -297,6 +358,16 @@ def main():
         "roofline": roofline,
     }
     h.close()
+    if rank == 0 and world == 1 and not args.no_live_traffic:
+        # (after the timed regions and with the handle released: the counter passes run in child processes)
+        try:
+            tb, detail = live_traffic(args)
+        except Exception as e:  # never lose the headline line over a side measurement
+            tb, detail = None, repr(e)
+        if tb is not None:
+            roofline["traffic"], roofline["traffic_detail"] = tb, detail
+        elif roofline["traffic_detail"] is not None:
+            roofline["traffic_detail"]["live_measurement_failed"] = detail
     if rank == 0 and world == 1 and not args.no_other_configs:
         out["other_configs"] = other_configs(_capi, synthetic)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

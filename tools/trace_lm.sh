@@ -3,7 +3,7 @@
 set -e
 export TMPDIR=/tmp
 rm -rf gpurun_out/prof_lm
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_lm -o lm -- python3 bench.py --steps 5 --warmup 2 --lm-steps 10 --no-cpu-baseline --no-other-configs > gpurun_out/prof_lm.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_lm -o lm -- python3 bench.py --steps 5 --warmup 2 --lm-steps 10 --no-cpu-baseline --no-other-configs --no-live-traffic > gpurun_out/prof_lm.log 2>&1
 python3 - <<'PY'
 import csv, glob
 f = glob.glob('gpurun_out/prof_lm/**/*kernel_stats.csv', recursive=True)[0]
