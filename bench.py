@@ -199,7 +199,7 @@ def live_traffic(args):
             try:
                 pr = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
                 try:
-                    pr.wait(timeout=180)
+                    pr.wait(timeout=90)
                 except subprocess.TimeoutExpired:
                     os.killpg(pr.pid, signal.SIGKILL)      # the process group started here, nothing else
                     pr.wait()
