@@ -541,7 +541,11 @@ int bcr_plan_for(BaHandle *h) {
     if (h->bcr_state != 0) return BA_OK;
     const Symbolic &s = h->sym;
     h->bcr_state = -1;
-    if (!bcr_make_plan(s.n_free, s.upper_keys.data(), s.upper_keys.size(), h->bcr_plan)) return BA_OK;
+    try {
+        if (!bcr_make_plan(s.n_free, s.upper_keys.data(), s.upper_keys.size(), h->bcr_plan)) return BA_OK;
+    } catch (const std::bad_alloc &) {
+        return fail(BA_ERR_NOMEM, "out of host memory while planning the cyclic reduction");
+    }
     const BcrPlan &P = h->bcr_plan;
     std::vector<int32_t> tab;
     auto put = [&](const void *src, size_t ints) {
