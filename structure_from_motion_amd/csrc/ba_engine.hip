@@ -769,7 +769,10 @@ int build_structure(BaHandle *h, const HostProblem &hp, int n_cams, int n_points
     const char *msg = "";
     if ((e = analyze_structure(n_cams, n_points, n_obs, hp.cam_fixed.data(), hp.obs_cam.data(), hp.obs_pt.data(), h->sym, &msg)))
         return fail(e, "%s", msg);
+    const bool tm_on = getenv("BA_TIME") != nullptr;
+    double tl = now_ms();
     finalize_pattern(h->sym, {});
+    if (tm_on) { fprintf(stderr, "[create]   %-22s %7.2f ms\n", "finalize_pattern", now_ms() - tl); tl = now_ms(); }
     Symbolic &s = h->sym;
     hipStream_t st = h->stream;
     h->n_chunks = (int)s.ck_obs.size() - 1;
@@ -796,7 +799,10 @@ int build_structure(BaHandle *h, const HostProblem &hp, int n_cams, int n_points
     }
     HIPCHK(h->pair_entries.upload(s.pair_entries, st));
     HIPCHK(h->ck_pgrp.upload(s.ck_pgrp, st));
-    return alloc_work(h);
+    if (tm_on) { fprintf(stderr, "[create]   %-22s %7.2f ms\n", "index uploads", now_ms() - tl); tl = now_ms(); }
+    const int ea = alloc_work(h);
+    if (tm_on) fprintf(stderr, "[create]   %-22s %7.2f ms\n", "work buffers", now_ms() - tl);
+    return ea;
 }
 
 int create_impl(const BaProblem *prob, const BaOptions *opt, BaHandle *h) {
@@ -817,10 +823,17 @@ int create_impl(const BaProblem *prob, const BaOptions *opt, BaHandle *h) {
     HIPCHK(hipEventCreate(&h->ev1));
     HIPCHK(hipEventCreate(&h->ev2));
     HIPCHK(hipEventCreate(&h->ev3));
+    const bool tm_on = getenv("BA_TIME") != nullptr;
+    double tl = now_ms();
+    auto tick = [&](const char *what) { if (tm_on) { const double t = now_ms(); fprintf(stderr, "[create]   %-22s %7.2f ms\n", what, t - tl); tl = t; } };
+    tick("device, stream, events");
     HostProblem hp;
     if ((e = fetch_problem(prob, hp, false))) return e;
+    tick("fetch");
     if ((e = build_structure(h, hp, prob->n_cams, prob->n_points, prob->n_obs))) return e;
+    tick("structure + uploads");
     if ((e = upload_values(h, hp))) return e;
+    tick("values");
     h->t_setup_ms = now_ms() - t0;
     return BA_OK;
 }

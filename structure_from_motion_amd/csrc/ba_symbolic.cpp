@@ -18,8 +18,9 @@ namespace {
 // fn(lo, hi) over [0, n) on up to 8 host threads (large n only).  Used where the result does not depend on the split.
 template <typename F>
 void parallel_for(int64_t n, F fn) {
-    constexpr int T = 8;
-    if (n < 200000) {
+    const int T = (int)std::min<int64_t>(8, n / 100000);   // (threads cost tens of microseconds to start, and the counting pass
+                                                           // uses atomics: 100 k items each at least)
+    if (T < 2) {
         fn((int64_t)0, n);
         return;
     }
@@ -319,7 +320,7 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
         if (cur_pts > 0) close_chunk(p1, pstart[p1]);
     };
     constexpr int CHUNK_THREADS = 8;
-    const int n_parts = s.n_pts_chunked >= 40000 ? CHUNK_THREADS : 1;
+    const int n_parts = std::max(1, std::min(CHUNK_THREADS, s.n_pts_chunked / 4000));   // (the reference's own sizes: 4-5 parts)
     std::vector<Part> parts(n_parts);
     {
         std::vector<int> cut(n_parts + 1, 0);
