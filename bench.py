@@ -93,11 +93,15 @@ def other_configs(_capi, synthetic):
         ids, image_data, pts = synthetic.to_image_data(p)
         for name, fn in (("wall_ms_final_ba_dict_api", lambda d: BA.final_ba(d, pts, ids, verbose=False)),
                          ("wall_ms_final_ba_session", lambda d: BASession().final_ba(d, pts, ids, verbose=False))):
-            d = dict(image_data)
-            t0 = time.perf_counter()
-            with contextlib.redirect_stdout(io.StringIO()):
-                _pts, _d, ok = fn(d)
-            out["temple_final_ba"][name] = (time.perf_counter() - t0) * 1e3
+            times = []
+            for _rep in range(3):      # (every call starts from the driver's containers again; best of three, the first
+                d = dict(image_data)   # call also pays one-time costs of the process)
+                t0 = time.perf_counter()
+                with contextlib.redirect_stdout(io.StringIO()):
+                    _pts, _d, ok = fn(d)
+                times.append((time.perf_counter() - t0) * 1e3)
+            out["temple_final_ba"][name] = min(times)
+            out["temple_final_ba"][name + "_first_call"] = times[0]
             out["temple_final_ba"][name.replace("wall_ms", "ok")] = bool(ok)
     except Exception as e:  # never lose the headline line over a side measurement
         out["temple_final_ba"]["host_api_error"] = repr(e)
