@@ -429,6 +429,10 @@ __global__ void k_bcr_gather(int n_blocks, int m, int NB, const int32_t *__restr
 
 // ------------------------------------------------------------------------------------------------ factor
 #define BA_BCR_DWAVES 4
+#ifndef BA_BCR_UPD_WAVES
+#define BA_BCR_UPD_WAVES 1   // waves (= output tiles) per workgroup of k_bcr_update: 1, 2, 4, 8, 16 measured -- 0.406, 0.415, 0.427, 0.442,
+                           // 0.474 ms per solve on the Venice shape (a workgroup holds its slots until its last wave is done)
+#endif
 #ifndef BA_BCR_GROUP
 #define BA_BCR_GROUP 4
 #endif
@@ -683,9 +687,9 @@ __global__ __launch_bounds__(64 * (NT + BA_BCR_DWAVES)) void k_bcr_factor(const 
 // slower, 10 instead of 5.5 us on the upper levels: what an update waits for is the latency of its first loads, the
 // blocks were written by other XCDs a kernel ago, and a short wave exposes it once.)
 template <int NT>
-__global__ __launch_bounds__(256) void k_bcr_update(int n_ops, const BcrOp *__restrict__ ops, double *__restrict__ D,
+__global__ __launch_bounds__(64 * BA_BCR_UPD_WAVES) void k_bcr_update(int n_ops, const BcrOp *__restrict__ ops, double *__restrict__ D,
                                                     double *__restrict__ G, double *__restrict__ bv) {
-    constexpr int NB = 16 * NT, KQ = NB / 4, TASKS = NT * NT + NT, WGS = (TASKS + 3) / 4;
+    constexpr int NB = 16 * NT, KQ = NB / 4, TASKS = NT * NT + NT, WGS = (TASKS + BA_BCR_UPD_WAVES - 1) / BA_BCR_UPD_WAVES;
     // workgroups are dealt round-robin over the 8 XCDs, each with an L2 of its own: renumbered so that the workgroups of
     // one update (they share its operand blocks) run on ONE XCD
     const int per_xcd = (n_ops * WGS + 7) / 8;
@@ -693,7 +697,7 @@ __global__ __launch_bounds__(256) void k_bcr_update(int n_ops, const BcrOp *__re
     if (wg >= n_ops * WGS) return;
     const BcrOp op = ops[wg / WGS];
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
-    const int task = (wg % WGS) * 4 + (tid >> 6);
+    const int task = (wg % WGS) * BA_BCR_UPD_WAVES + (tid >> 6);
     if (task >= TASKS) return;
     const size_t nb2 = (size_t)NB * NB;
     if (task < NT * NT) {
@@ -860,14 +864,14 @@ inline hipError_t bcr_solve_launch_t(hipStream_t st, const BcrPlan &P, const Bcr
                            d.DG, d.bv, d.info);
     }
     const size_t lds = bcr_factor_lds_bytes(NT);
-    constexpr int WGS = (NT * NT + NT + 3) / 4;
+    constexpr int WGS = (NT * NT + NT + BA_BCR_UPD_WAVES - 1) / BA_BCR_UPD_WAVES;
     const int nl = P.levels();
     for (int l = 0; l < nl; ++l) {
         const int ne_l = P.lvl_elim[l + 1] - P.lvl_elim[l], no_l = P.lvl_op[l + 1] - P.lvl_op[l];
         hipLaunchKernelGGL(k_bcr_factor<NT>, dim3(2 * ne_l), dim3(64 * (NT + BA_BCR_DWAVES)), lds, st, d.elims + P.lvl_elim[l], D, G,
                            d.bv, d.linv, d.info);
         if (no_l > 0)
-            hipLaunchKernelGGL(k_bcr_update<NT>, dim3(8 * ((no_l * WGS + 7) / 8)), dim3(256), 0, st, no_l, d.ops + P.lvl_op[l], D, G, d.bv);
+            hipLaunchKernelGGL(k_bcr_update<NT>, dim3(8 * ((no_l * WGS + 7) / 8)), dim3(64 * BA_BCR_UPD_WAVES), 0, st, no_l, d.ops + P.lvl_op[l], D, G, d.bv);
     }
     for (int l = nl - 1; l >= 0; --l) {
         const int ne_l = P.lvl_elim[l + 1] - P.lvl_elim[l];
