@@ -608,6 +608,12 @@ int step_tail(BaHandle *h, const int *solve_info) {
         if (h->n_chunks > 0) hipLaunchKernelGGL(k_backsub, dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, B);
         if (h->n_heavy > 0) hipLaunchKernelGGL(k_backsub_heavy, dim3(h->n_heavy), dim3(256), 0, st, B, heavy_args(h));
     }
+    if (!h->coll) {   // single GPU: reductions, |x|^2 of the unobserved points and the decision in ONE launch
+        hipLaunchKernelGGL(k_reduce_decide, dim3(1), dim3(1024), 0, st, h->n_chunks + h->n_heavy, h->ck_part.p, s.n_cams, h->cam_part.p,
+                           h->step_sums.p, h->cam_sums.p, h->state.p, h->x2_const, h->opt.ftol, h->opt.xtol, h->opt.gtol, solve_info);
+        HIPCHK(hipGetLastError());
+        return BA_OK;
+    }
     hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(1024), 0, st, h->n_chunks + h->n_heavy, 4, h->ck_part.p, h->step_sums.p);
     hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(1024), 0, st, s.n_cams, 2, h->cam_part.p, h->cam_sums.p);
     // |x|^2 of this rank's unobserved points joins the partial sums BEFORE the all-reduce so that

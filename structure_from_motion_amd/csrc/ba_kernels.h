@@ -919,8 +919,8 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_backsub(const BacksubArgs A) {
 // ------------------------------------------------------------------ deterministic reductions + LM control
 // out[k] = sum over i of in[i*stride + k] (k < stride <= 4), fixed order -> bitwise reproducible.  ONE block of 1024
 // threads; all loads of a trip (two rows, every column) are issued before any is used.
-__global__ __launch_bounds__(1024) void k_reduce_sum(int n, int stride, const double *__restrict__ in, double *__restrict__ out) {
-    __shared__ double red[16][4];
+__device__ __forceinline__ void reduce_sum_1024(int n, int stride, const double *__restrict__ in, double *__restrict__ out,
+                                                double (*red)[4]) {
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     for (int i = threadIdx.x; i < n; i += 2048) {
         const int i2 = i + 1024, j2 = i2 < n ? i2 : i;
@@ -948,6 +948,10 @@ __global__ __launch_bounds__(1024) void k_reduce_sum(int n, int stride, const do
         for (int w = 0; w < 16; ++w) t += red[w][threadIdx.x];
         out[threadIdx.x] = t;
     }
+}
+__global__ __launch_bounds__(1024) void k_reduce_sum(int n, int stride, const double *__restrict__ in, double *__restrict__ out) {
+    __shared__ double red[16][4];
+    reduce_sum_1024(n, stride, in, out, red);
 }
 __global__ void k_reduce_max(int n, const double *__restrict__ in, double *__restrict__ out) {
     __shared__ double red[4];
@@ -1072,8 +1076,8 @@ __global__ __launch_bounds__(256) void k_state_after_build(LmState *st, const do
 // step[0..3] = pred, F_trial, |dp|^2, |x_p|^2 (all-reduced); cams[0..1] = |dc|^2, |x_c|^2 (replicated)
 // solve_info (may be null): != 0 when the direct solver met a non-positive pivot -- the step is void, the state stays
 // as it is and the host repeats the step with PCG
-__global__ void k_decide(LmState *st, const double *step, const double *cams, double x2_const, double ftol, double xtol,
-                         double gtol, const int *solve_info) {
+__device__ __forceinline__ void decide_step(LmState *st, const double *step, const double *cams, double x2_const, double ftol,
+                                            double xtol, double gtol, const int *solve_info) {
     // scipy's gtol test on the gradient of the linearisation this step started from.  It sits here, not on the host, so
     // that the host does not have to read the state back after every build: a step queued behind a build whose gradient
     // was already small is void (state untouched), terminate = 1 tells the host.
@@ -1120,6 +1124,26 @@ __global__ void k_decide(LmState *st, const double *step, const double *cams, do
     else if (ftol_ok) term = 2;
     else if (xtol_ok) term = 3;
     st->terminate = term;
+}
+__global__ void k_decide(LmState *st, const double *step, const double *cams, double x2_const, double ftol, double xtol,
+                         double gtol, const int *solve_info) {
+    decide_step(st, step, cams, x2_const, ftol, xtol, gtol, solve_info);
+}
+// (single GPU) the tail of a trial step in one launch: the two fixed-order reductions of the per-chunk and per-camera
+// partial sums (same order as k_reduce_sum), |x|^2 of the unobserved points, and the decision
+__global__ __launch_bounds__(1024) void k_reduce_decide(int n_ck, const double *__restrict__ ck_part, int n_cams,
+                                                        const double *__restrict__ cam_part, double *__restrict__ step_sums,
+                                                        double *__restrict__ cam_sums, LmState *st, double x2_const, double ftol,
+                                                        double xtol, double gtol, const int *solve_info) {
+    __shared__ double red[16][4];
+    reduce_sum_1024(n_ck, 4, ck_part, step_sums, red);
+    __syncthreads();
+    reduce_sum_1024(n_cams, 2, cam_part, cam_sums, red);
+    __syncthreads();   // (thread 0 reads what threads 0 .. 3 wrote: same workgroup, behind a barrier)
+    if (threadIdx.x == 0) {
+        step_sums[3] += x2_const;
+        decide_step(st, step_sums, cam_sums, 0.0, ftol, xtol, gtol, solve_info);
+    }
 }
 
 // ------------------------------------------------------------------ evaluation kernels, caller's order
