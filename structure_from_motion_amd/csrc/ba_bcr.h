@@ -382,9 +382,12 @@ inline bool bcr_make_plan(int nf, const int64_t *keys, size_t nk, BcrPlan &P) {
 inline size_t bcr_matrix_doubles(const BcrPlan &P) { return (size_t)(P.m + P.n_slots) * P.nb * P.nb; }
 inline size_t bcr_vec_doubles(const BcrPlan &P) { return (size_t)P.m * P.nb; }
 inline size_t bcr_linv_doubles(const BcrPlan &P) { return (size_t)P.m * P.nt * 256; }
+#ifndef BA_BCR_BACK_THREADS
+#define BA_BCR_BACK_THREADS 1024   // threads of k_bcr_back: 256 / 512 / 1024 measured, 0.439 / 0.408 / 0.390 ms per solve (Venice shape)
+#endif
 inline size_t bcr_back_lds_bytes(int nt) {
     const int nb = 16 * nt;
-    return ((size_t)nb * nb + (size_t)nt * 256 + (size_t)(512 / nb) * nb + nb + 16) * sizeof(double);
+    return ((size_t)nb * nb + (size_t)nt * 256 + (size_t)(BA_BCR_BACK_THREADS / nb) * nb + nb + 16) * sizeof(double);
 }
 inline size_t bcr_factor_lds_bytes(int nt) {
     const int nb = 16 * nt;
@@ -746,11 +749,11 @@ __global__ __launch_bounds__(64 * BA_BCR_UPD_WAVES) void k_bcr_update(int n_ops,
 
 // ------------------------------------------------------------------------------------------------ backward
 template <int NT>
-__global__ __launch_bounds__(512) void k_bcr_back(const BcrElim *__restrict__ elims, const double *__restrict__ D,
+__global__ __launch_bounds__(BA_BCR_BACK_THREADS) void k_bcr_back(const BcrElim *__restrict__ elims, const double *__restrict__ D,
                                                   const double *__restrict__ G, double *__restrict__ bv,
                                                   const double *__restrict__ Linv16, const int32_t *__restrict__ pos_f,
                                                   double *__restrict__ xout) {
-    constexpr int NB = 16 * NT, PARTS = 512 / NB, RP = (NB + PARTS - 1) / PARTS;
+    constexpr int NB = 16 * NT, PARTS = BA_BCR_BACK_THREADS / NB, RP = (NB + PARTS - 1) / PARTS;
     extern __shared__ double bcr_smem[];
     double *sL = bcr_smem;             // NB x NB: L_k (every global load of the kernel is issued up front: the blocked
     double *sLi = sL + NB * NB;        // NT x 256: inverses of its diagonal tiles     substitution below runs out of LDS)
@@ -765,8 +768,8 @@ __global__ __launch_bounds__(512) void k_bcr_back(const BcrElim *__restrict__ el
     const int fcam = tid < 6 * (NB / 6) ? pos_f[el.k * (NB / 6) + tid / 6] : -1;   // the camera of unknown tid of this block
     {
         const double *L = D + el.k * nb2, *li = Linv16 + (size_t)el.k * NT * 256;
-        for (int e = tid; e < NB * NB; e += 512) sL[e] = L[e];
-        for (int e = tid; e < NT * 256; e += 512) sLi[e] = li[e];
+        for (int e = tid; e < NB * NB; e += BA_BCR_BACK_THREADS) sL[e] = L[e];
+        for (int e = tid; e < NT * 256; e += BA_BCR_BACK_THREADS) sLi[e] = li[e];
     }
     if (tid < PARTS * NB) {
         const int part = tid / NB, c = tid - part * NB;
@@ -875,7 +878,7 @@ inline hipError_t bcr_solve_launch_t(hipStream_t st, const BcrPlan &P, const Bcr
     }
     for (int l = nl - 1; l >= 0; --l) {
         const int ne_l = P.lvl_elim[l + 1] - P.lvl_elim[l];
-        hipLaunchKernelGGL(k_bcr_back<NT>, dim3(ne_l), dim3(512), bcr_back_lds_bytes(NT), st, d.elims + P.lvl_elim[l], D, G, d.bv, d.linv, d.pos_f, x);
+        hipLaunchKernelGGL(k_bcr_back<NT>, dim3(ne_l), dim3(BA_BCR_BACK_THREADS), bcr_back_lds_bytes(NT), st, d.elims + P.lvl_elim[l], D, G, d.bv, d.linv, d.pos_f, x);
     }
     return hipGetLastError();
 }
