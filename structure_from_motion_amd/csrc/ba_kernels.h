@@ -639,6 +639,114 @@ __global__ void k_finalize(int nf, const double *__restrict__ U, const double *_
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f < nf) finalize_camera(f, U, gc, gred, S, diag_slot, Minv, cam_gmax, st);
 }
+// apply_jl_block (diagonal block) + apply_jl_camera + finalize_camera of ONE camera with everything kept in registers
+// between the three: every operand is requested once, up front, and every result stored once -- the three functions one
+// after the other wait for their own stores to come back from memory three times (the camera threads' chain of
+// dependent round trips set the time of k_apply_finalize: 18 us).  Same arithmetic, same order.
+__device__ __forceinline__ void apply_finalize_camera(int f, const int *__restrict__ free_cam, const double *__restrict__ aux,
+                                                      double *__restrict__ S, double *__restrict__ U, double *__restrict__ gc,
+                                                      double *__restrict__ gred, const int *__restrict__ diag_slot,
+                                                      double *__restrict__ Minv, double *__restrict__ cam_gmax,
+                                                      const LmState *__restrict__ st) {
+    const int slot = diag_slot[f], cam = free_cam[f];
+    const double lam = st->lambda;
+    double *blk = &S[(size_t)slot * 36], *u = &U[(size_t)f * 21], *g1 = &gc[(size_t)f * 6], *g2 = &gred[(size_t)f * 6];
+    const double *J = aux + (size_t)cam * BA_CAM_AUX + 9;
+    double B[36], ub[21], ga[6], gb[6], jl[9];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) B[k] = blk[k];
+#pragma unroll
+    for (int k = 0; k < 21; ++k) ub[k] = u[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { ga[k] = g1[k]; gb[k] = g2[k]; }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) jl[k] = J[k];
+    double T3[18];
+    // --- the diagonal block of S: D^T B D
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) T3[r * 6 + c] = jl[r] * B[c] + jl[3 + r] * B[6 + c] + jl[6 + r] * B[12 + c];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) B[k] = T3[k];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const double b0 = B[r * 6], b1 = B[r * 6 + 1], b2 = B[r * 6 + 2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) B[r * 6 + c] = b0 * jl[c] + b1 * jl[3 + c] + b2 * jl[6 + c];
+    }
+    // --- U = D^T U' D, g = D^T g'
+    double Ub[36];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = r; c < 6; ++c) Ub[r * 6 + c] = Ub[c * 6 + r] = ub[ut6(r, c)];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) T3[r * 6 + c] = jl[r] * Ub[c] + jl[3 + r] * Ub[6 + c] + jl[6 + r] * Ub[12 + c];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) Ub[k] = T3[k];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const double b0 = Ub[r * 6], b1 = Ub[r * 6 + 1], b2 = Ub[r * 6 + 2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Ub[r * 6 + c] = b0 * jl[c] + b1 * jl[3 + c] + b2 * jl[6 + c];
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = r; c < 6; ++c) {
+            ub[ut6(r, c)] = (r < 3 && c < 3 && r != c) ? 0.5 * (Ub[r * 6 + c] + Ub[c * 6 + r]) : Ub[r * 6 + c];
+            u[ut6(r, c)] = ub[ut6(r, c)];
+        }
+    {
+        const double a0 = ga[0], a1 = ga[1], a2 = ga[2], b0 = gb[0], b1 = gb[1], b2 = gb[2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            ga[r] = jl[r] * a0 + jl[3 + r] * a1 + jl[6 + r] * a2;
+            gb[r] = jl[r] * b0 + jl[3 + r] * b1 + jl[6 + r] * b2;
+        }
+    }
+    // --- finalize: damped U onto the diagonal block, block-Jacobi inverse, reduced gradient
+    double A[36];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i; j < 6; ++j) {
+            double v = ub[ut6(i, j)];
+            if (i == j) v += lam * fmin(fmax(v, BA_D_MIN), BA_D_MAX);
+            const double a = B[i * 6 + j] + v;
+            const double bsym = (i == j) ? a : B[j * 6 + i] + v;
+            A[i * 6 + j] = a;
+            A[j * 6 + i] = bsym;
+        }
+#pragma unroll
+    for (int k = 0; k < 36; ++k) blk[k] = A[k];
+    double Ms[36];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) Ms[i * 6 + j] = 0.5 * (A[i * 6 + j] + A[j * 6 + i]);
+    double Mi[36];
+    if (!spd6_inverse(Ms, Mi)) {
+#pragma unroll
+        for (int k = 0; k < 36; ++k) Mi[k] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Mi[i * 6 + i] = 1.0 / fmax(fabs(Ms[i * 6 + i]), 1e-300);
+    }
+#pragma unroll
+    for (int k = 0; k < 36; ++k) Minv[(size_t)f * 36 + k] = Mi[k];
+    double gm = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        g1[i] = ga[i];
+        g2[i] = gb[i] + ga[i];
+        gm = fmax(gm, fabs(ga[i]));
+    }
+    cam_gmax[f] = gm;
+}
+
 // k_apply_jl and k_finalize in one launch (single-GPU build pass: nothing has to happen between them).  A camera's
 // thread transforms its own diagonal block (the block threads leave the diagonal keys alone) and finalises it.
 __global__ void k_apply_finalize(int nf, int n_upper, const long long *__restrict__ keys, const int *__restrict__ free_cam,
@@ -649,10 +757,7 @@ __global__ void k_apply_finalize(int nf, int n_upper, const long long *__restric
     if (t < n_upper) {
         if ((int)(keys[t] >> 32) != (int)(keys[t] & 0xffffffff)) apply_jl_block(t, keys, free_cam, aux, S);
     } else if (t < n_upper + nf) {
-        const int f = t - n_upper;
-        apply_jl_block(diag_slot[f], keys, free_cam, aux, S);
-        apply_jl_camera(f, free_cam, aux, U, gc, gred);
-        finalize_camera(f, U, gc, gred, S, diag_slot, Minv, cam_gmax, st);
+        apply_finalize_camera(t - n_upper, free_cam, aux, S, U, gc, gred, diag_slot, Minv, cam_gmax, st);
     }
 }
 
