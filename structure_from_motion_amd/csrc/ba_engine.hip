@@ -252,6 +252,7 @@ struct BaHandle {
     double *S = nullptr, *U = nullptr, *gc = nullptr, *gred = nullptr, *sums = nullptr;
     DevBuf<int> diag_slot, bsr_row, bsr_col, bsr_src;
     DevBuf<double> Minv, cam_gmax, gm2;
+    bool minv_valid = false;   // Minv belongs to the S of the latest build
     DevBuf<double> pt_linv, pt_u, ck_cost, ck_gmax, ck_part, cam_part, step_sums, cam_sums;
     DevBuf<double> dbg_v, dbg_gp;
     DevBuf<unsigned long long> stamps;  // diagnostic (ba_debug_stamps)
@@ -407,8 +408,8 @@ int do_build(BaHandle *h, bool timed) {
         // single GPU: nothing has to happen between the kernels behind the build -- two launches instead of four
         if (nf > 0)
             hipLaunchKernelGGL(k_apply_finalize, dim3((h->n_upper + nf + 127) / 128), dim3(128), 0, st, nf, h->n_upper, h->upper_keys.p,
-                               h->free_cam.p, h->aux[h->cur].p, h->S, h->U, h->gc, h->gred, h->diag_slot.p, h->Minv.p,
-                               h->cam_gmax.p, h->state.p);
+                               h->free_cam.p, h->aux[h->cur].p, h->S, h->U, h->gc, h->gred, h->diag_slot.p, h->cam_gmax.p, h->state.p);
+        h->minv_valid = false;   // (do_pcg computes the block-Jacobi inverse when it needs it)
         hipLaunchKernelGGL(k_totals_state, dim3(1), dim3(1024), 0, st, h->n_chunks + h->n_heavy, h->ck_cost.p, h->ck_gmax.p, h->sums,
                            h->gm2.p, h->state.p, nf, h->cam_gmax.p);
     } else {
@@ -424,6 +425,7 @@ int do_build(BaHandle *h, bool timed) {
                                h->free_cam.p, h->aux[h->cur].p, h->S, h->U, h->gc, h->gred);
             hipLaunchKernelGGL(k_finalize, dim3((nf + 63) / 64), dim3(64), 0, st, nf, h->U, h->gc, h->gred, h->S, h->diag_slot.p,
                                h->Minv.p, h->cam_gmax.p, h->state.p);
+            h->minv_valid = true;
         }
         hipLaunchKernelGGL(k_state_after_build, dim3(1), dim3(256), 0, st, h->state.p, h->sums, h->gm2.p, nf, h->cam_gmax.p);
     }
@@ -445,6 +447,10 @@ int do_pcg(BaHandle *h, int *iters_out) {
     *iters_out = 0;
     if (nf == 0) return BA_OK;
     const int nb_cam = (nf + 255) / 256, nb_row = (nf + 3) / 4;
+    if (!h->minv_valid) {
+        hipLaunchKernelGGL(k_block_jacobi, dim3((nf + 63) / 64), dim3(64), 0, st, nf, h->S, h->diag_slot.p, h->Minv.p);
+        h->minv_valid = true;
+    }
     HIPCHK(hipMemsetAsync(h->pcg_sc.p, 0, sizeof(PcgScalars), st));
     hipLaunchKernelGGL(k_pcg_init, dim3(nb_cam), dim3(256), 0, st, nf, h->gred, h->Minv.p, h->px.p, h->pr.p, h->pz.p,
                        h->pcg_sc.p);

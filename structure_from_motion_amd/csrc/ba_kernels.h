@@ -646,8 +646,7 @@ __global__ void k_finalize(int nf, const double *__restrict__ U, const double *_
 __device__ __forceinline__ void apply_finalize_camera(int f, const int *__restrict__ free_cam, const double *__restrict__ aux,
                                                       double *__restrict__ S, double *__restrict__ U, double *__restrict__ gc,
                                                       double *__restrict__ gred, const int *__restrict__ diag_slot,
-                                                      double *__restrict__ Minv, double *__restrict__ cam_gmax,
-                                                      const LmState *__restrict__ st) {
+                                                      double *__restrict__ cam_gmax, const LmState *__restrict__ st) {
     const int slot = diag_slot[f], cam = free_cam[f];
     const double lam = st->lambda;
     double *blk = &S[(size_t)slot * 36], *u = &U[(size_t)f * 21], *g1 = &gc[(size_t)f * 6], *g2 = &gred[(size_t)f * 6];
@@ -723,20 +722,8 @@ __device__ __forceinline__ void apply_finalize_camera(int f, const int *__restri
         }
 #pragma unroll
     for (int k = 0; k < 36; ++k) blk[k] = A[k];
-    double Ms[36];
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = 0; j < 6; ++j) Ms[i * 6 + j] = 0.5 * (A[i * 6 + j] + A[j * 6 + i]);
-    double Mi[36];
-    if (!spd6_inverse(Ms, Mi)) {
-#pragma unroll
-        for (int k = 0; k < 36; ++k) Mi[k] = 0.0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) Mi[i * 6 + i] = 1.0 / fmax(fabs(Ms[i * 6 + i]), 1e-300);
-    }
-#pragma unroll
-    for (int k = 0; k < 36; ++k) Minv[(size_t)f * 36 + k] = Mi[k];
+    // (the block-Jacobi inverse is the PCG's business: k_block_jacobi computes it from the stored block when a PCG
+    // solve is about to run -- with a direct solver nobody reads it)
     double gm = 0.0;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -752,13 +739,36 @@ __device__ __forceinline__ void apply_finalize_camera(int f, const int *__restri
 __global__ void k_apply_finalize(int nf, int n_upper, const long long *__restrict__ keys, const int *__restrict__ free_cam,
                                  const double *__restrict__ aux, double *__restrict__ S, double *__restrict__ U,
                                  double *__restrict__ gc, double *__restrict__ gred, const int *__restrict__ diag_slot,
-                                 double *__restrict__ Minv, double *__restrict__ cam_gmax, const LmState *__restrict__ st) {
+                                 double *__restrict__ cam_gmax, const LmState *__restrict__ st) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n_upper) {
         if ((int)(keys[t] >> 32) != (int)(keys[t] & 0xffffffff)) apply_jl_block(t, keys, free_cam, aux, S);
     } else if (t < n_upper + nf) {
-        apply_finalize_camera(t - n_upper, free_cam, aux, S, U, gc, gred, diag_slot, Minv, cam_gmax, st);
+        apply_finalize_camera(t - n_upper, free_cam, aux, S, U, gc, gred, diag_slot, cam_gmax, st);
     }
+}
+
+// block-Jacobi preconditioner of the PCG: inverse of the (symmetrised) finalised diagonal block of every free camera,
+// the same arithmetic as in finalize_camera.  Launched by do_pcg when the single-GPU build pass left it out.
+__global__ void k_block_jacobi(int nf, const double *__restrict__ S, const int *__restrict__ diag_slot, double *__restrict__ Minv) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nf) return;
+    const double *blk = &S[(size_t)diag_slot[f] * 36];
+    double A[36], Ms[36], Mi[36];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) A[k] = blk[k];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) Ms[i * 6 + j] = 0.5 * (A[i * 6 + j] + A[j * 6 + i]);
+    if (!spd6_inverse(Ms, Mi)) {
+#pragma unroll
+        for (int k = 0; k < 36; ++k) Mi[k] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Mi[i * 6 + i] = 1.0 / fmax(fabs(Ms[i * 6 + i]), 1e-300);
+    }
+#pragma unroll
+    for (int k = 0; k < 36; ++k) Minv[(size_t)f * 36 + k] = Mi[k];
 }
 
 // ------------------------------------------------------------------ PCG on S x = -g_red
