@@ -17,6 +17,16 @@ def _init(rank, world, port):
     return dist
 
 
+def _engine_problem():
+    """The problem of the engine workers: a 16-camera ring (dense solver) or, with BA_TEST_PROBLEM=street203, a street
+    chain of 203 cameras -- beyond the one-workgroup dense solver, so AUTO takes the block cyclic reduction, which every
+    rank then runs on the all-reduced system (what a multi-GPU run of the bench workload does)."""
+    from structure_from_motion_amd import synthetic
+    if os.environ.get("BA_TEST_PROBLEM") == "street203":
+        return synthetic.make_street(203, 5000, 22000, seed=51, outlier_frac=0.01), 25
+    return synthetic.make_ring(16, 600, seed=8, mean_track=4.0, outlier_frac=0.02), 80
+
+
 def oracle_sharded_step(rank, world, port, out_dir):
     """CPU: one damped Gauss-Newton step of a point-sharded problem with the oracle's math; the
     partial reduced systems are summed with a gloo all-reduce exactly as dist.py does on the GPU."""
@@ -76,14 +86,14 @@ def engine_sharded_solve(rank, world, port, out_dir):
     torch.cuda.set_device(0)
     from structure_from_motion_amd import synthetic
     from structure_from_motion_amd import dist as badist
-    p = synthetic.make_ring(16, 600, seed=8, mean_track=4.0, outlier_frac=0.02)
+    p, max_iter = _engine_problem()
     sh, pidx = badist.shard_points(p, rank, world)
-    h = badist.create_sharded_handle(sh, rank, world, loss="huber", f_scale=1.0, max_iter=80, device=0,
+    h = badist.create_sharded_handle(sh, rank, world, loss="huber", f_scale=1.0, max_iter=max_iter, device=0,
                                      verbose=int(os.environ.get("BA_TEST_VERBOSE", "0")))
     s = h.run()
     cp, pts = h.state()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), cp=cp, pts=pts, pidx=pidx, cost=s["final_cost"], status=s["status"],
-             iters=s["iterations"])
+             iters=s["iterations"], pcg=s["pcg_iterations"])
     h.close()
     dist.destroy_process_group()
 
@@ -100,17 +110,18 @@ def engine_nccl_single_rank(rank, world, port, out_dir):
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     from structure_from_motion_amd import synthetic
     from structure_from_motion_amd import dist as badist
-    p = synthetic.make_ring(16, 600, seed=8, mean_track=4.0, outlier_frac=0.02)
+    p, max_iter = _engine_problem()
     sh, pidx = badist.shard_points(p, 0, 1)
     out = {}
     for name, ordered, native in (("blocking", False, False), ("ordered", True, False), ("native", True, True)):
         h = badist.create_sharded_handle(sh, 0, 1, stream_ordered=ordered, force_collectives=True, native=native, loss="huber",
-                                         f_scale=1.0, max_iter=80, device=0)
+                                         f_scale=1.0, max_iter=max_iter, device=0)
         ms_pass, _ = h.build_bench(1e-4, warmup=2, reps=20)          # back-to-back passes, collectives in between
         s = h.run()
         cp, pts = h.state()
         out[name + "_cp"], out[name + "_pts"] = cp, pts
         out[name + "_cost"], out[name + "_status"], out[name + "_ms"] = s["final_cost"], s["status"], ms_pass
+        out[name + "_pcg"], out[name + "_iters"] = s["pcg_iterations"], s["iterations"]
         h.close()
     np.savez(os.path.join(out_dir, "nccl1.npz"), **out)
     dist.destroy_process_group()

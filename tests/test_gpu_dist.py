@@ -44,6 +44,30 @@ def test_rccl_callbacks_blocking_and_stream_ordered(gpu, tmp_path):
           % (float(r["blocking_ms"]), float(r["ordered_ms"]), float(r["native_ms"])))
 
 
+def test_sharded_solves_use_the_cyclic_reduction_beyond_the_dense_size(gpu, tmp_path, monkeypatch):
+    """203 cameras on a street: AUTO's linear solver is the block cyclic reduction, run by every rank on the all-reduced
+    reduced camera system.  Two gloo ranks, and the library's own RCCL binding with one rank, against the single handle:
+    no PCG iteration anywhere, same number of LM steps, same minimum."""
+    monkeypatch.setenv("BA_TEST_PROBLEM", "street203")
+    p = synthetic.make_street(203, 5000, 22000, seed=51, outlier_frac=0.01)
+    arr = _capi.Arrays.from_dict(p)
+    s = _capi.solve(arr, loss="huber", f_scale=1.0, max_iter=25)
+    assert s["pcg_iterations"] == 0 and s["accepted"] >= 3
+    mp.spawn(engine_sharded_solve, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert int(r0["pcg"]) == 0 and int(r1["pcg"]) == 0
+    assert int(r0["iters"]) == int(r1["iters"]) == s["iterations"] and int(r0["status"]) == int(r1["status"]) == s["status"]
+    np.testing.assert_array_equal(r0["cp"], r1["cp"])
+    assert abs(float(r0["cost"]) - s["final_cost"]) <= 1e-8 * s["final_cost"]
+    assert np.allclose(r0["cp"], arr.cam_pose, rtol=1e-6, atol=1e-6)
+    mp.spawn(engine_nccl_single_rank, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    r = np.load(tmp_path / "nccl1.npz")
+    for name in ("blocking", "ordered", "native"):
+        assert int(r[name + "_pcg"]) == 0 and int(r[name + "_iters"]) == s["iterations"] and int(r[name + "_status"]) == s["status"]
+        assert abs(float(r[name + "_cost"]) - s["final_cost"]) <= 1e-8 * s["final_cost"]
+        assert np.allclose(r[name + "_cp"], arr.cam_pose, rtol=1e-6, atol=1e-6)
+
+
 def test_rank_without_observations_stays_in_step(gpu, tmp_path):
     mp.spawn(engine_sharded_empty_rank, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     r0, r1 = np.load(tmp_path / "empty0.npz"), np.load(tmp_path / "empty1.npz")
