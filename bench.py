@@ -325,7 +325,7 @@ def main():
     achieved = alg / (ms_kernel * 1e-3) / 1e9
     traffic = None
     tf = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tf):
+    if os.path.exists(tf) and world == 1:   # (recorded for the whole problem on one GPU: says nothing about a shard's launch)
         traffic = json.load(open(tf)).get(f"{args.workload}@{args.scale:g}")
     roofline = {"bound": "hbm", "kernel": "k_build", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
