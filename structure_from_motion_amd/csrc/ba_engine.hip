@@ -272,7 +272,9 @@ struct BaHandle {
     bool dense_attr_set = false;
     DevBuf<LmState> state;
     LmState hstate{};
+    LmState *hstate_pinned = nullptr;   // page-locked landing place of read_state
     PcgScalars hpcg{};
+    PcgScalars *hpcg_pinned = nullptr;   // page-locked landing place of the PCG's convergence poll
     // collectives
     BaCollectiveFn coll = nullptr;
     void *coll_user = nullptr;
@@ -293,6 +295,8 @@ struct BaHandle {
         if (ev1) (void)hipEventDestroy(ev1);
         if (ev2) (void)hipEventDestroy(ev2);
         if (ev3) (void)hipEventDestroy(ev3);
+        if (hstate_pinned) (void)hipHostFree(hstate_pinned);
+        if (hpcg_pinned) (void)hipHostFree(hpcg_pinned);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -435,8 +439,12 @@ int do_build(BaHandle *h, bool timed) {
 }
 
 int read_state(BaHandle *h) {
-    HIPCHK(hipMemcpyAsync(&h->hstate, h->state.p, sizeof(LmState), hipMemcpyDeviceToHost, h->stream));
+    // (into page-locked memory: a copy to pageable memory goes through the runtime's staging buffer, and this read-back is
+    // the one host round trip of every LM step)
+    if (!h->hstate_pinned) HIPCHK(hipHostMalloc((void **)&h->hstate_pinned, sizeof(LmState), hipHostMallocDefault));
+    HIPCHK(hipMemcpyAsync(h->hstate_pinned, h->state.p, sizeof(LmState), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    h->hstate = *h->hstate_pinned;
     return BA_OK;
 }
 
@@ -467,8 +475,10 @@ int do_pcg(BaHandle *h, int *iters_out) {
             hipLaunchKernelGGL(k_pcg_b, dim3(nb_cam), dim3(256), 0, st, nf, it, h->Minv.p, p_out, h->pqv.p, h->px.p,
                                h->pr.p, h->pz.p, h->pcg_sc.p);
         }
-        HIPCHK(hipMemcpyAsync(&h->hpcg, h->pcg_sc.p, sizeof(PcgScalars), hipMemcpyDeviceToHost, st));
+        if (!h->hpcg_pinned) HIPCHK(hipHostMalloc((void **)&h->hpcg_pinned, sizeof(PcgScalars), hipHostMallocDefault));
+        HIPCHK(hipMemcpyAsync(h->hpcg_pinned, h->pcg_sc.p, sizeof(PcgScalars), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
+        h->hpcg = *h->hpcg_pinned;
         if (h->hpcg.done != 0.0) break;
     }
     *iters_out = (int)h->hpcg.iters;
