@@ -606,7 +606,8 @@ int step_tail(BaHandle *h, const int *solve_info) {
     if (h->coll && s.n_free > 0 && (e = call_coll(h, h->px.p, (int64_t)s.n_free * 6, BA_BROADCAST0))) return e;
     const int cur = h->cur, tr = cur ^ 1;
     hipLaunchKernelGGL(k_cam_update, dim3((s.n_cams + 63) / 64), dim3(64), 0, st, s.n_cams, h->cam_free.p, h->pose[cur].p,
-                       h->intr.p, h->px.p, h->pose[tr].p, h->aux[tr].p, h->cam_part.p);
+                       h->intr.p, h->px.p, h->pose[tr].p, h->aux[tr].p, h->cam_part.p, h->aux[cur].p, h->pr.p);
+    // (h->pr, the PCG's residual vector, is free between two solves: it carries the step in the local rotation tangent)
     if (h->n_chunks + h->n_heavy > 0) {
         BacksubArgs B{};
         B.aux = h->aux[cur].p; B.aux_t = h->aux[tr].p;
@@ -614,7 +615,8 @@ int step_tail(BaHandle *h, const int *solve_info) {
         B.o_cam = h->o_cam.p; B.o_pt = h->o_pt.p; B.o_xy = h->o_xy.p;
         B.cam_free = h->cam_free.p;
         B.ck_obs = h->ck_obs.p; B.ck_pt = h->ck_pt.p;
-        B.dx = h->px.p;
+        B.dx = h->pr.p;
+        B.dx_rvec = h->px.p;
         B.pt_linv = h->pt_linv.p; B.pt_u = h->pt_u.p;
         B.ck_part = h->ck_part.p;
         B.loss = h->opt.loss;

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void k_backsub_heavy(const BacksubArgs A, cons
         double a0 = 0.0, a1 = 0.0;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            const double d = A.dx[(size_t)f * 6 + i];
+            const double d = A.dx_rvec[(size_t)f * 6 + i];
             a0 += Ln.Jc[0][i] * d; a1 += Ln.Jc[1][i] * d;
         }
         const double wa0 = Ln.wh[0] * a0, wa1 = Ln.wh[1] * a1;
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void k_backsub_heavy(const BacksubArgs A, cons
         if (f >= 0) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
-                const double d = A.dx[(size_t)f * 6 + i];
+                const double d = A.dx_rvec[(size_t)f * 6 + i];
                 a0 += Ln.Jc[0][i] * d; a1 += Ln.Jc[1][i] * d;
             }
         }

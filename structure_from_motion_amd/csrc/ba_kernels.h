@@ -901,20 +901,33 @@ __global__ __launch_bounds__(256) void k_pcg_b(int nf, int it, const double *__r
 }
 
 // ------------------------------------------------------------------ trial cameras
+// dx_loc (may be null): the step in the local rotation tangent, (Jl dr, dt) per free camera -- what the chunk
+// back-substitution multiplies its local-tangent camera blocks with (one 3x3 product per camera here instead of one per
+// observation there)
 __global__ void k_cam_update(int n_cams, const int *__restrict__ cam_free, const double *__restrict__ pose,
                              const double *__restrict__ intr, const double *__restrict__ dx, double *__restrict__ pose_t,
-                             double *__restrict__ aux_t, double *__restrict__ cam_part) {
+                             double *__restrict__ aux_t, double *__restrict__ cam_part, const double *__restrict__ aux,
+                             double *__restrict__ dx_loc) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_cams) return;
     const int f = cam_free[c];
-    double ps[6], d2 = 0.0, x2 = 0.0;
+    double ps[6], dd[6], d2 = 0.0, x2 = 0.0;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const double v = pose[6 * (size_t)c + i];
         double d = 0.0;
         if (f >= 0) { d = dx[(size_t)f * 6 + i]; d2 += d * d; x2 += v * v; }
+        dd[i] = d;
         ps[i] = v + d;
         pose_t[6 * (size_t)c + i] = ps[i];
+    }
+    if (f >= 0 && dx_loc) {
+        const double *J = aux + (size_t)c * BA_CAM_AUX + 9;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            dx_loc[(size_t)f * 6 + r] = J[3 * r] * dd[0] + J[3 * r + 1] * dd[1] + J[3 * r + 2] * dd[2];
+            dx_loc[(size_t)f * 6 + 3 + r] = dd[3 + r];
+        }
     }
     cam_aux_from_pose(ps, intr + 4 * (size_t)c, aux_t + (size_t)c * BA_CAM_AUX);
     cam_part[2 * (size_t)c] = d2;
@@ -930,7 +943,9 @@ struct BacksubArgs {
     const double *o_xy;
     const int *cam_free;
     const int *ck_obs, *ck_pt;
-    const double *dx;               // camera step [n_free*6]
+    const double *dx;               // camera step [n_free*6]: in the local rotation tangent for k_backsub, in rvec
+                                    // coordinates for k_backsub_heavy (dx_rvec)
+    const double *dx_rvec;
     const double *pt_linv, *pt_u;
     double *ck_part;                // [n_chunks*4]: pred, F_trial, |dp|^2, |x_p|^2
     int loss;
@@ -938,22 +953,13 @@ struct BacksubArgs {
     const LmState *state;
 };
 
-__global__ __launch_bounds__(CHUNK_OBS) void k_backsub(const BacksubArgs A) {
+__global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_backsub(const BacksubArgs A) {
     __shared__ double sP[CHUNK_PTS * 3];
     __shared__ double sRed[4][4];
     const int ck = blockIdx.x, tid = threadIdx.x;
     const int ob = A.ck_obs[ck], nobs = A.ck_obs[ck + 1] - ob;
     const int pb = A.ck_pt[ck], npts = A.ck_pt[ck + 1] - pb;
     for (int i = tid; i < npts * 3; i += CHUNK_OBS) sP[i] = 0.0;
-    // the per-point operands of the middle phase are requested now, not behind the barrier that precedes their use
-    double li[6] = {0, 0, 0, 0, 0, 0}, uu[3] = {0, 0, 0}, pp[3] = {0, 0, 0};
-    if (tid < npts) {
-        const size_t p = (size_t)(pb + tid);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) li[k] = A.pt_linv[p * 6 + k];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { uu[k] = A.pt_u[p * 3 + k]; pp[k] = A.points[3 * p + k]; }
-    }
     __syncthreads();
     const bool act = tid < nobs;
     int lp = 0, cam = 0;
@@ -964,7 +970,7 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_backsub(const BacksubArgs A) {
         const int p = A.o_pt[o];
         lp = p - pb;
         CamAux ca;
-        load_aux(A.aux, cam, ca);
+        load_aux_local(A.aux, cam, ca);   // (local rotation tangent; A.dx is the step in the same coordinates, k_cam_update)
         X0 = A.points[3 * (size_t)p]; X1 = A.points[3 * (size_t)p + 1]; X2 = A.points[3 * (size_t)p + 2];
         const double2 xy = reinterpret_cast<const double2 *>(A.o_xy)[o];
         uo = xy.x; vo = xy.y;
@@ -984,6 +990,16 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_backsub(const BacksubArgs A) {
         const double wa0 = h0 * a0, wa1 = h1 * a1;
 #pragma unroll
         for (int j = 0; j < 3; ++j) atomicAdd(&sP[lp * 3 + j], Jp[0][j] * wa0 + Jp[1][j] * wa1);
+    }
+    // the per-point operands of the middle phase are requested in front of the barrier that precedes their use (not at the
+    // top of the kernel: twelve more live doubles through the linearisation cost the fifth wave per SIMD)
+    double li[6] = {0, 0, 0, 0, 0, 0}, uu[3] = {0, 0, 0}, pp[3] = {0, 0, 0};
+    if (tid < npts) {
+        const size_t p = (size_t)(pb + tid);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) li[k] = A.pt_linv[p * 6 + k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { uu[k] = A.pt_u[p * 3 + k]; pp[k] = A.points[3 * p + k]; }
     }
     __syncthreads();
     double dp2 = 0.0, xp2 = 0.0;
