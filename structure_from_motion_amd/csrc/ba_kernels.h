@@ -1053,24 +1053,22 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(5, 5)
 __device__ __forceinline__ void reduce_sum_1024(int n, int stride, const double *__restrict__ in, double *__restrict__ out,
                                                 double (*red)[4]) {
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int i = threadIdx.x; i < n; i += 2048) {
-        const int i2 = i + 1024, j2 = i2 < n ? i2 : i;
-        double a[4], b[4];
+    for (int i = threadIdx.x; i < n; i += 4096) {   // four rows per trip: sixteen independent loads in flight
+        double a[4][4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int kk = k < stride ? k : 0;
-            a[k] = in[(size_t)i * stride + kk];
-            b[k] = in[(size_t)j2 * stride + kk];
+        for (int u = 0; u < 4; ++u) {
+            const int iu = i + 1024 * u, ju = iu < n ? iu : i;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[u][k] = in[(size_t)ju * stride + (k < stride ? k : 0)];
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            acc[k] += a[k];
-            acc[k] += i2 < n ? b[k] : 0.0;
-        }
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] += i + 1024 * u < n ? a[u][k] : 0.0;
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const double v = wave_sum(acc[k]);
+        const double v = wave_sum_dpp(acc[k]);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
     }
     __syncthreads();
