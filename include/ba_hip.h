@@ -78,7 +78,9 @@ typedef struct BaOptions {
     double pcg_tol;        /* relative residual of the reduced-camera-system solve (default 1e-8) */
     int32_t pcg_max_iter;  /* default 500 */
     int32_t linear_solver; /* BA_SOLVER_*: AUTO = dense Cholesky up to 128 free cameras; block cyclic reduction when
-                              co-visible free cameras are at most 21 apart in camera order, as a chain or a closed ring;
+                              co-visible free cameras are at most 21 apart along a chain or a closed ring (in camera order,
+                              or in an order the planner finds from the co-visibility graph when the numbering is not
+                              along the trajectory);
                               blocked dense Cholesky for a (nearly) full pattern up to 2048 free cameras; block-Jacobi
                               PCG otherwise.  BANDED_CHOLESKY (chains, at most 16 apart) only on request */
     int32_t verbose;       /* 0 silent, 1 summary, 2 per-iteration table (<- verbose, :219) */
