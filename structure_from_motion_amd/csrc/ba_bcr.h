@@ -14,18 +14,24 @@
 // the banded / dense solvers to rounding.
 //
 // Kernels (NB = 16 NT scalars per block, NT = 2, 4, 6 or 8 MFMA tiles):
+//   k_bcr_gather  every element of the diagonal blocks and the initial couplings from its 6x6 block of S (a host-built
+//                 table), the right-hand side and the pivot flag: one launch, no memset, no scatter.
 //   k_bcr_factor  two workgroups per eliminated block (one per neighbour, both factor D_k): D_k lives in LDS and is
-//                 factored right-looking in 16-column steps -- ONE wave factors the 16x16 diagonal tile in registers (a
-//                 row per lane, readlane broadcasts) and inverts it, three more waves do panel and trailing tiles on the
-//                 fp64 matrix cores (v_mfma_f64_16x16x4_f64); the neighbour's coupling block rides along as NT
-//                 16-row strips, one wave each, whose tiles never leave the accumulators (a strip visits LDS only to
-//                 turn an accumulator tile into an MFMA operand); the right-hand side is one more row of D_k.
-//   k_bcr_update  one wave per 16x16 output tile, operands straight from L2: lane (row, q) loads a CONTIGUOUS quarter
-//                 of its row (the k-index of an MFMA lane is free as long as both operands agree), so a wave reads whole
-//                 cache lines and needs no LDS.
-//   k_bcr_back    one workgroup per block of the level.
+//                 factored right-looking in 16-column steps.  ONE wave owns the serial chain: it factors the 16x16
+//                 diagonal tile in registers (a row per lane, readlane broadcasts, the tile's inverse in the same sweep),
+//                 computes the next diagonal tile's panel and update itself and goes on factoring while three more waves
+//                 apply the step to the rest of D_k on the fp64 matrix cores (v_mfma_f64_16x16x4_f64); the neighbour's
+//                 coupling block rides along as NT 16-row strips, one wave each, whose tiles never leave the
+//                 accumulators (a strip visits LDS only to turn an accumulator tile into an MFMA operand); the
+//                 right-hand side is one more row of D_k.
+//   k_bcr_update  one wave (= one workgroup) per 16x16 output tile, operands straight from L2: lane (row, l4) loads
+//                 pieces of its row such that four lanes read 64 contiguous bytes (the k-index of an MFMA lane is free
+//                 as long as both operands agree); no LDS.  Workgroups are renumbered so that one update stays on one XCD.
+//   k_bcr_back    one workgroup per block of the level, every global load up front, blocked substitution out of LDS.
 // The schedule (which block, which neighbours, which coupling slot, per level) is planned on the host once per pattern
-// (bcr_make_plan) and executed from tables.
+// (bcr_make_plan) and executed from tables.  The planner takes the cameras in index order, else along a chain coordinate
+// computed from the co-visibility graph, else in reverse Cuthill-McKee order: the numbering of the cameras does not
+// have to follow the trajectory.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -52,7 +58,7 @@ constexpr int32_t BCR_SRC_ZERO = -1, BCR_SRC_UNIT = -2;
 struct BcrPlan {
     bool ok = false, cyclic = false;
     int nf = 0, m = 0, nt = 0, nb = 0, band = 0, n_slots = 0, n_init_slots = 0;
-    bool reordered = false;          // the cameras are taken in reverse Cuthill-McKee order, not in index order
+    bool reordered = false;          // the cameras are not taken in index order (bcr_chain_order / bcr_rcm_order)
     std::vector<int32_t> blk_start;  // [m + 1] first POSITION (in the elimination order of the cameras) of each block
     std::vector<int32_t> pos_f;      // [m * (nb / 6)] free camera at (block, offset), -1 = padding
     std::vector<int32_t> cam_blk;    // [nf] block << 8 | offset inside the block, per free camera
