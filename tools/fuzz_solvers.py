@@ -21,7 +21,7 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 bad = 0
 for seed in range(seed0, seed0 + n_cases):
     rng = np.random.default_rng(seed)
-    nc = int(rng.integers(135, 700))
+    nc = int(rng.integers(135, int(sys.argv[3]) if len(sys.argv) > 3 else 700))
     mt = int(rng.integers(3, 21))
     ring = rng.random() < 0.35
     shuffle = rng.random() < 0.4
