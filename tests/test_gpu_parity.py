@@ -547,6 +547,38 @@ def test_append_on_a_dense_track_problem(gpu):
         assert s1["iterations"] == s2["iterations"] and abs(s1["final_cost"] - s2["final_cost"]) <= 1e-8 * s2["final_cost"]
 
 
+def test_append_replans_the_cyclic_reduction(gpu):
+    """ba_append on a long chain solved by the block cyclic reduction: the schedule belongs to the camera pattern, so
+    the grown handle has to plan again (more blocks, another level) -- same LM path as a fresh handle, and no PCG
+    iteration on either (a stale schedule would either be refused or solve the wrong system)."""
+    full = synthetic.make_street(300, 9000, 40000, seed=11, outlier_frac=0.01)
+    n_first = 170
+    last = np.zeros(len(full["points"]), np.int64); np.maximum.at(last, full["obs_pt"], full["obs_cam"])
+    order = np.argsort(last, kind="stable"); inv = np.argsort(order)
+    pts = full["points"][order]; opt_ = inv[full["obs_pt"]]
+    n1 = int((last[order] < n_first).sum())
+    m1 = opt_ < n1
+    first = dict(cam_pose=full["cam_pose"][:n_first], cam_intr=full["cam_intr"][:n_first], cam_fixed=full["cam_fixed"][:n_first],
+                 points=pts[:n1], obs_cam=full["obs_cam"][m1], obs_pt=opt_[m1].astype(np.int32), obs_xy=full["obs_xy"][m1])
+    grown = dict(cam_pose=full["cam_pose"], cam_intr=full["cam_intr"], cam_fixed=full["cam_fixed"], points=pts,
+                 obs_cam=np.concatenate([full["obs_cam"][m1], full["obs_cam"][~m1]]),
+                 obs_pt=np.concatenate([opt_[m1], opt_[~m1]]).astype(np.int32),
+                 obs_xy=np.concatenate([full["obs_xy"][m1], full["obs_xy"][~m1]]))
+    kw = dict(linear_solver="cyclic_reduction", max_iter=12)
+    with _capi.Handle(_capi.Arrays.from_dict(first), **kw) as h, _capi.Handle(_capi.Arrays.from_dict(grown), **kw) as fresh, \
+            _capi.Handle(_capi.Arrays.from_dict(grown), linear_solver="dense_cholesky", max_iter=12) as dense:
+        s0 = h.run()
+        assert s0["pcg_iterations"] == 0 and s0["iterations"] > 0
+        assert h.append(_capi.Arrays.from_dict(grown)) is True
+        s1, s2, s3 = h.run(), fresh.run(), dense.run()
+        assert s1["pcg_iterations"] == 0 and s2["pcg_iterations"] == 0
+        assert s1["status"] == s2["status"] == s3["status"] and s1["iterations"] == s2["iterations"] == s3["iterations"]
+        assert s1["initial_cost"] == s2["initial_cost"]
+        assert abs(s1["final_cost"] - s2["final_cost"]) <= 1e-9 * s2["final_cost"]
+        assert abs(s1["final_cost"] - s3["final_cost"]) <= 1e-8 * s3["final_cost"]
+        np.testing.assert_allclose(h.state()[0], fresh.state()[0], rtol=1e-6, atol=1e-8)
+
+
 def test_heavy_points_and_slotless_cameras(gpu):
     """Tracks longer than a chunk (3 landmarks seen by all 270 cameras: heavy-point kernels) next to windows of up to
     60 cameras (more than a chunk has LDS camera tiles: the slot-less path), 5 % outliers: reduced system against the
