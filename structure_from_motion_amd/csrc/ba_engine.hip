@@ -623,7 +623,10 @@ int step_tail(BaHandle *h, const int *solve_info) {
         B.state = h->state.p;
         B.inv_fs2 = 1.0 / (h->opt.f_scale * h->opt.f_scale);
         B.half_fs2 = 0.5 * h->opt.f_scale * h->opt.f_scale;
-        if (h->n_chunks > 0) hipLaunchKernelGGL(k_backsub, dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, B);
+        if (h->n_chunks > 0) {
+            if (h->opt.loss == BA_LOSS_HUBER) hipLaunchKernelGGL((k_backsub<BA_LOSS_HUBER>), dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, B);
+            else hipLaunchKernelGGL((k_backsub<-1>), dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, B);
+        }
         if (h->n_heavy > 0) hipLaunchKernelGGL(k_backsub_heavy, dim3(h->n_heavy), dim3(256), 0, st, B, heavy_args(h));
     }
     if (!h->coll) {   // single GPU: reductions, |x|^2 of the unobserved points and the decision in ONE launch

@@ -953,33 +953,38 @@ struct BacksubArgs {
     const LmState *state;
 };
 
+// LOSS: the robust loss as a compile-time constant (huber), or -1 for A.loss -- as in k_build.  The chunk's loads are
+// issued unconditionally (clamped indices), and every barrier orders LDS only: the stores of the trial points and the
+// loads of the next phase stay in flight across them.
+template <int LOSS>
 __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_backsub(const BacksubArgs A) {
     __shared__ double sP[CHUNK_PTS * 3];
     __shared__ double sRed[4][4];
     const int ck = blockIdx.x, tid = threadIdx.x;
     const int ob = A.ck_obs[ck], nobs = A.ck_obs[ck + 1] - ob;
     const int pb = A.ck_pt[ck], npts = A.ck_pt[ck + 1] - pb;
-    for (int i = tid; i < npts * 3; i += CHUNK_OBS) sP[i] = 0.0;
-    __syncthreads();
+    const int loss = LOSS >= 0 ? LOSS : A.loss;
     const bool act = tid < nobs;
-    int lp = 0, cam = 0;
-    double r0 = 0, r1 = 0, w0 = 0, w1 = 0, h0 = 0, h1 = 0, a0 = 0, a1 = 0, Jp[2][3], X0 = 0, X1 = 0, X2 = 0, uo = 0, vo = 0;
-    if (act) {
-        const int o = ob + tid;
-        cam = A.o_cam[o];
-        const int p = A.o_pt[o];
-        lp = p - pb;
-        CamAux ca;
-        load_aux_local(A.aux, cam, ca);   // (local rotation tangent; A.dx is the step in the same coordinates, k_cam_update)
-        X0 = A.points[3 * (size_t)p]; X1 = A.points[3 * (size_t)p + 1]; X2 = A.points[3 * (size_t)p + 2];
-        const double2 xy = reinterpret_cast<const double2 *>(A.o_xy)[o];
-        uo = xy.x; vo = xy.y;
+    const int o = ob + (act ? tid : 0);
+    const int cam = A.o_cam[o];
+    const int p = A.o_pt[o];
+    const double2 xy = reinterpret_cast<const double2 *>(A.o_xy)[o];
+    CamAux ca;
+    load_aux_local(A.aux, cam, ca);   // (local rotation tangent; A.dx is the step in the same coordinates, k_cam_update)
+    const double X0 = A.points[3 * (size_t)p], X1 = A.points[3 * (size_t)p + 1], X2 = A.points[3 * (size_t)p + 2];
+    const int f = A.cam_free[cam];
+    const double floor_now = A.state->floor;
+    for (int i = tid; i < npts * 3; i += CHUNK_OBS) sP[i] = 0.0;
+    lds_barrier();
+    const int lp = act ? p - pb : 0;
+    const double uo = xy.x, vo = xy.y;
+    double r0 = 0, r1 = 0, w0 = 0, w1 = 0, h0 = 0, h1 = 0, a0 = 0, a1 = 0, Jp[2][3];
+    {
         ObsLin L;
-        linearize(ca, X0, X1, X2, uo, vo, A.loss, A.inv_fs2, A.state->floor, L);
+        linearize(ca, X0, X1, X2, uo, vo, loss, A.inv_fs2, floor_now, L);
         r0 = L.r[0]; r1 = L.r[1]; w0 = L.w[0]; w1 = L.w[1]; h0 = L.wh[0]; h1 = L.wh[1];
 #pragma unroll
         for (int j = 0; j < 3; ++j) { Jp[0][j] = L.Jp[0][j]; Jp[1][j] = L.Jp[1][j]; }
-        const int f = A.cam_free[cam];
         if (f >= 0) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
@@ -987,24 +992,26 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(5, 5)
                 a0 += L.Jc[0][i] * d; a1 += L.Jc[1][i] * d;
             }
         }
-        const double wa0 = h0 * a0, wa1 = h1 * a1;
+        if (act) {
+            const double wa0 = h0 * a0, wa1 = h1 * a1;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) atomicAdd(&sP[lp * 3 + j], Jp[0][j] * wa0 + Jp[1][j] * wa1);
+            for (int j = 0; j < 3; ++j) atomicAdd(&sP[lp * 3 + j], Jp[0][j] * wa0 + Jp[1][j] * wa1);
+        }
     }
     // the per-point operands of the middle phase are requested in front of the barrier that precedes their use (not at the
     // top of the kernel: twelve more live doubles through the linearisation cost the fifth wave per SIMD)
-    double li[6] = {0, 0, 0, 0, 0, 0}, uu[3] = {0, 0, 0}, pp[3] = {0, 0, 0};
-    if (tid < npts) {
-        const size_t p = (size_t)(pb + tid);
+    double li[6], uu[3], pp[3];
+    {
+        const size_t q = (size_t)(pb + (tid < npts ? tid : 0));
 #pragma unroll
-        for (int k = 0; k < 6; ++k) li[k] = A.pt_linv[p * 6 + k];
+        for (int k = 0; k < 6; ++k) li[k] = A.pt_linv[q * 6 + k];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { uu[k] = A.pt_u[p * 3 + k]; pp[k] = A.points[3 * p + k]; }
+        for (int k = 0; k < 3; ++k) { uu[k] = A.pt_u[q * 3 + k]; pp[k] = A.points[3 * q + k]; }
     }
-    __syncthreads();
+    lds_barrier();
     double dp2 = 0.0, xp2 = 0.0;
     if (tid < npts) {
-        const size_t p = (size_t)(pb + tid);
+        const size_t q = (size_t)(pb + tid);
         const double i00 = li[0], i10 = li[1], i11 = li[2], i20 = li[3], i21 = li[4], i22 = li[5];
         const double s0 = sP[tid * 3], s1 = sP[tid * 3 + 1], s2 = sP[tid * 3 + 2];
         const double y0 = uu[0] + i00 * s0;
@@ -1015,23 +1022,37 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(5, 5)
         const double d2 = -(i22 * y2);
         sP[tid * 3] = d0; sP[tid * 3 + 1] = d1; sP[tid * 3 + 2] = d2;
         const double p0 = pp[0], p1 = pp[1], p2 = pp[2];
-        A.points_t[3 * p] = p0 + d0; A.points_t[3 * p + 1] = p1 + d1; A.points_t[3 * p + 2] = p2 + d2;
+        A.points_t[3 * q] = p0 + d0; A.points_t[3 * q + 1] = p1 + d1; A.points_t[3 * q + 2] = p2 + d2;
         dp2 = d0 * d0 + d1 * d1 + d2 * d2;
         xp2 = p0 * p0 + p1 * p1 + p2 * p2;
     }
-    __syncthreads();
+    // the trial camera of the last phase (R, t, intrinsics), requested in front of the barrier (the point operands are dead
+    // by now; any earlier and the kernel spills at five waves per SIMD)
+    double2 tq[9];
+    {
+        const double2 *q = reinterpret_cast<const double2 *>(A.aux_t + (size_t)cam * BA_CAM_AUX);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) tq[k] = q[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tq[5 + k] = q[9 + k];
+    }
+    lds_barrier();
     double pred = 0.0, ft = 0.0;
     if (act) {
         const double d0 = sP[lp * 3], d1 = sP[lp * 3 + 1], d2 = sP[lp * 3 + 2];
         const double jd0 = a0 + Jp[0][0] * d0 + Jp[0][1] * d1 + Jp[0][2] * d2;
         const double jd1 = a1 + Jp[1][0] * d0 + Jp[1][1] * d1 + Jp[1][2] * d2;
         pred = -(jd0 * (w0 * r0 + 0.5 * h0 * jd0) + jd1 * (w1 * r1 + 0.5 * h1 * jd1));
-        double u, v;
-        project_only(A.aux_t, cam, X0 + d0, X1 + d1, X2 + d2, u, v);
+        const double Z0 = X0 + d0, Z1 = X1 + d1, Z2 = X2 + d2;
+        const double x = tq[0].x * Z0 + tq[0].y * Z1 + tq[1].x * Z2 + tq[5].x;
+        const double y = tq[1].y * Z0 + tq[2].x * Z1 + tq[2].y * Z2 + tq[5].y;
+        const double z = tq[3].x * Z0 + tq[3].y * Z1 + tq[4].x * Z2 + tq[6].x;
+        const double iz = (z != 0.0) ? 1.0 / z : 1.0;  // (project_only's arithmetic, operands loaded above)
+        const double u = tq[6].y * (x * iz) + tq[7].y, v = tq[7].x * (y * iz) + tq[8].x;
         const double e0 = u - uo, e1 = v - vo;
         double rho0, rho1, wd;
-        loss_eval(A.loss, e0 * e0 * A.inv_fs2, rho0, wd);
-        loss_eval(A.loss, e1 * e1 * A.inv_fs2, rho1, wd);
+        loss_eval(loss, e0 * e0 * A.inv_fs2, rho0, wd);
+        loss_eval(loss, e1 * e1 * A.inv_fs2, rho1, wd);
         ft = A.half_fs2 * (rho0 + rho1);
     }
     // four block sums behind ONE barrier: DPP wave sums (fixed order), then the four wave results per quantity
@@ -1043,7 +1064,7 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(5, 5)
         double *r = sRed[tid >> 6];
         r[0] = pred; r[1] = ft; r[2] = dp2; r[3] = xp2;
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < 4) A.ck_part[(size_t)ck * 4 + tid] = (sRed[0][tid] + sRed[1][tid]) + (sRed[2][tid] + sRed[3][tid]);
 }
 
