@@ -9,21 +9,23 @@
 //     any other row, so when the factorisation is done it holds y = L^-1 (-g) -- the forward substitution costs nothing;
 //     rows behind it are padding with a unit diagonal;
 //   * per block column k, three launches:
-//       k_big_potrf  ONE wave: Cholesky of the 64 x 64 diagonal block in registers (a row per lane) and the explicit
-//                    inverse of its factor (so that the panel solve below is a matrix product);
+//       k_big_potrf  ONE workgroup: Cholesky of the 64 x 64 diagonal block in LDS, 16-column steps with the serial chain
+//                    on one wave (as k_bcr_factor), and the explicit inverse of its factor (so that the panel solve
+//                    below is a matrix product);
 //       k_big_trsm   one workgroup per 64 rows below: panel <- panel Linv^T on the fp64 matrix cores;
 //       k_big_syrk   one workgroup per 64 x 64 tile of the trailing lower triangle: tile -= P_I P_J^T, 64 MFMAs
 //                    (v_mfma_f64_16x16x4_f64) per wave, operand tiles staged through LDS;
 //   * backward substitution L^T x = y, one launch per block column from the last to the first: every workgroup forms
 //     x_k = Linv_k^T y_k (64 x 64, redundantly) and takes x_k out of one earlier block of y (a contiguous 64 x 64 block
 //     row of L).
-// The diagonal-block factorisation is a serial chain of one wave (about 50 us per block) during which the chip idles:
-// a third of the solve at 10 k unknowns (see big_solve_launch for the look-ahead that was tried).
+// The diagonal-block factorisation, the panel solve and the backward step of a block column are short serial launches
+// (19 + 10 + 14 us) during which most of the chip idles: 7 of the 18 ms of a solve at 10 k unknowns.
 // About 4 n / 64 launches, queued without host synchronisation; a non-positive pivot sets
 // *info (the LM step is then void and repeated with PCG, as for the other direct solvers).
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "ba_bcr.h"    // bcr_potrf16, bcr_static_for
 #include "ba_dense.h"
 
 #define BA_DENSE_BIG_MAX 12288   // unknowns: 2048 free cameras; the matrix takes 1.2 GB
@@ -59,55 +61,117 @@ __global__ void k_big_init(int n, int M, const double *__restrict__ g, double *_
     else if (t < M) A[(size_t)t * M + t] = 1.0;
 }
 
-// Cholesky of the 64 x 64 diagonal block at k0 and the inverse of its factor.  ONE wave, no LDS, no barriers: lane r
-// holds row r of the block in registers (statically indexed: the loops are fully unrolled), the pivot row's entries
-// travel through readlane.  (The first version kept the block in LDS with three barriers per column: 87 us per block,
-// a quarter of the whole factorisation at 10 k unknowns.)
-__device__ __forceinline__ double big_readlane(double v, int lane) {
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
-}
-__global__ __launch_bounds__(64) void k_big_potrf(int k0, int M, double *__restrict__ A, double *__restrict__ Linv,
-                                                  int *__restrict__ info) {
-    constexpr int NB = BA_BIG_NB;
-    const int lane = threadIdx.x;
-    double row[NB];
-    {
-        const double *src = &A[(size_t)(k0 + lane) * M + k0];
-#pragma unroll
-        for (int c = 0; c < NB; ++c) row[c] = src[c];   // (entries right of the diagonal are never used)
+// Cholesky of the 64 x 64 diagonal block at k0 and the inverse of its factor: ONE workgroup of four waves, the block in
+// LDS, factored right-looking in 16-column steps the way k_bcr_factor does it (ba_bcr.h) -- wave 0 owns the serial chain
+// (bcr_potrf16: the 16 x 16 diagonal tile and the inverse of its factor in registers, readlane broadcasts), then its own
+// panel tile (s+1, s) and the update of tile (s+1, s+1), and is already factoring the next diagonal tile while waves
+// 1..3 apply step s to the rest (panel tiles = products with the tile's inverse, trailing tiles, all MFMA).  The inverse
+// X = L^-1 of the whole block follows tile by tile, by distance from the diagonal:
+//   X_ii = (from the chain),   X_ij = -X_ii sum_{k = j .. i-1} L_ik X_kj
+// -- the accumulator of the inner sum IS the second MFMA's B operand (element q of a lane = row l4 + 4q, which the
+// k index of an MFMA lane is free to mean), so nothing is staged in between.
+// (History: the block in LDS with three barriers per column, 87 us per block; one wave with a row of 64 per lane in
+// registers, 54 us -- a third of the whole solve at 10 k unknowns; this version: see DESIGN.md.)
+__global__ __launch_bounds__(256) void k_big_potrf(int k0, int M, double *__restrict__ A, double *__restrict__ Linv,
+                                                   int *__restrict__ info) {
+    constexpr int NB = BA_BIG_NB, NT = NB / 16, LDD = NB + 1;
+    __shared__ double sD[NB * LDD];
+    __shared__ double sLinv[NT * 272];                  // diagonal tiles of the inverse, 16 x 17 each
+    __shared__ double sXo[(NT * (NT - 1) / 2) * 272];   // tiles below the diagonal: (i, j) at i (i - 1) / 2 + j
+    auto xtile = [&](int i, int j) -> double * { return i == j ? sLinv + i * 272 : sXo + (i * (i - 1) / 2 + j) * 272; };
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int r = e / NB, c = e - r * NB;
+        sD[r * LDD + c] = A[(size_t)(k0 + r) * M + k0 + c];   // (entries right of the diagonal are never used)
     }
+    __syncthreads();
     int bad = 0;
+    auto panel_tile = [&](int i, int s) {   // (i, s) <- (i, s) Linv_s^T
+        mfma_d4 w = mfma_d4{0.0, 0.0, 0.0, 0.0};
+        double aq[4], bq[4];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const double d = big_readlane(row[j], j);
-        if (!(d > 0.0) && bad == 0) bad = k0 + j + 1;
-        const double inv = 1.0 / sqrt(d > 0.0 ? d : 1.0);
-        row[j] *= inv;                                   // column j of L (lanes above the diagonal hold junk, unused)
+        for (int q = 0; q < 4; ++q) { aq[q] = sD[(16 * i + l15) * LDD + 16 * s + 4 * q + l4]; bq[q] = sLinv[s * 272 + l15 * 17 + 4 * q + l4]; }
 #pragma unroll
-        for (int c = j + 1; c < NB; ++c) {
-            const double lc = big_readlane(row[j], c);   // L[c][j]
-            row[c] = fma(-row[j], lc, row[c]);           // A[r][c] -= L[r][j] L[c][j]   (used for r >= c)
+        for (int q = 0; q < 4; ++q) w = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[q], bq[q], w, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) sD[(16 * i + l4 + 4 * v) * LDD + 16 * s + l15] = w[v];
+    };
+    auto trailing_tile = [&](int i, int j, int s) {   // (i, j) -= (i, s) (j, s)^T
+        double aq[4], bq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            aq[q] = -sD[(16 * i + l15) * LDD + 16 * s + 4 * q + l4];
+            bq[q] = sD[(16 * j + l15) * LDD + 16 * s + 4 * q + l4];
         }
+        mfma_d4 w;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) w[v] = sD[(16 * i + l4 + 4 * v) * LDD + 16 * j + l15];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[q], bq[q], w, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) sD[(16 * i + l4 + 4 * v) * LDD + 16 * j + l15] = w[v];
+    };
+    // two barriers per step: B1 releases the factor + inverse of tile (s, s), B2 the panel (i, s)
+    if (wv == 0) {
+        bcr_static_for<0, NT>([&](auto step_c) {
+            constexpr int s = decltype(step_c)::value;
+            if (bcr_potrf16(&sD[(16 * s + l15) * LDD + 16 * s], sLinv + s * 272, nullptr, lane)) bad = 1;
+            __syncthreads();
+            if (s + 1 < NT) {
+                panel_tile(s + 1, s);
+                band_wave_sync();
+                trailing_tile(s + 1, s + 1, s);
+            }
+            __syncthreads();
+        });
+    } else {
+        bcr_static_for<0, NT>([&](auto step_c) {
+            constexpr int s = decltype(step_c)::value;
+            __syncthreads();
+#pragma unroll
+            for (int i = s + 2; i < NT; ++i)
+                if ((i - s - 2) % 3 == wv - 1) panel_tile(i, s);
+            __syncthreads();
+            int task = 0;
+#pragma unroll
+            for (int i = s + 1; i < NT; ++i) {
+#pragma unroll
+                for (int j = s + 1; j <= i; ++j) {
+                    if (i == s + 1 && j == s + 1) continue;   // (wave 0 has done it)
+                    if (wv == 1 + task % 3) trailing_tile(i, j, s);
+                    ++task;
+                }
+            }
+        });
     }
-    {
-        double *dst = &A[(size_t)(k0 + lane) * M + k0];
+    __syncthreads();
 #pragma unroll
-        for (int c = 0; c < NB; ++c)
-            if (c <= lane) dst[c] = row[c];
+    for (int d = 1; d < NT; ++d) {
+        if (wv < NT - d) {
+            const int j = wv, i = wv + d;
+            mfma_d4 w = mfma_d4{0.0, 0.0, 0.0, 0.0};
+            for (int k = j; k < i; ++k) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    w = __builtin_amdgcn_mfma_f64_16x16x4f64(sD[(16 * i + l15) * LDD + 16 * k + 4 * q + l4],
+                                                             xtile(k, j)[(4 * q + l4) * 17 + l15], w, 0, 0, 0);
+            }
+            mfma_d4 x = mfma_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                x = __builtin_amdgcn_mfma_f64_16x16x4f64(-sLinv[i * 272 + l15 * 17 + 4 * q + l4], w[q], x, 0, 0, 0);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) xtile(i, j)[(l4 + 4 * v) * 17 + l15] = x[v];
+        }
+        __syncthreads();
     }
-    // X = L^-1, lane = column c of X: x_r = (delta_rc - sum_{k < r} L[r][k] x_k) / L[r][r], L[r][k] broadcast from lane r
-    double x[NB];
-#pragma unroll
-    for (int r = 0; r < NB; ++r) {
-        double sum = (r == lane) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < r; ++k) sum = fma(-big_readlane(row[k], r), x[k], sum);
-        x[r] = sum / big_readlane(row[r], r);
-        if (r < lane) x[r] = 0.0;                        // (upper triangle of the inverse)
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int r = e / NB, c = e - r * NB;
+        if (c <= r) A[(size_t)(k0 + r) * M + k0 + c] = sD[r * LDD + c];
+        Linv[e] = c <= r ? xtile(r >> 4, c >> 4)[(r & 15) * 17 + (c & 15)] : 0.0;
     }
-#pragma unroll
-    for (int r = 0; r < NB; ++r) Linv[r * NB + lane] = x[r];
-    if (lane == 0 && bad != 0) atomicCAS(info, 0, bad);
+    if (tid == 0 && bad) atomicCAS(info, 0, k0 + 1);
 }
 
 // panel rows r0 .. r0+63 (r0 = k0 + 64 (1 + blockIdx.x)): P <- P Linv^T.  256 threads = 4 waves of 16 rows.
@@ -248,7 +312,7 @@ inline hipError_t big_solve_launch(hipStream_t st, int n, int n_upper, const lon
     for (int kb = 0; kb < nblk; ++kb) {
         const int k0 = kb * BA_BIG_NB, below = nblk - 1 - kb;
         double *li = Linv + (size_t)kb * BA_BIG_NB * BA_BIG_NB;
-        hipLaunchKernelGGL(k_big_potrf, dim3(1), dim3(64), 0, st, k0, M, A, li, info);
+        hipLaunchKernelGGL(k_big_potrf, dim3(1), dim3(256), 0, st, k0, M, A, li, info);
         if (below > 0) {
             hipLaunchKernelGGL(k_big_trsm, dim3(below), dim3(256), 0, st, k0, M, A, li);
             hipLaunchKernelGGL(k_big_syrk, dim3(below * (below + 1) / 2), dim3(256), 0, st, k0, M, A);
