@@ -299,7 +299,10 @@ __global__ __launch_bounds__(256) void k_big_back(int kb, int n, int M, double *
 // (Tried: look-ahead over a second stream -- the diagonal factorisation of column k + 1 beside the bulk of column k's
 // update.  The streams did overlap, but the lone factorisation wave needs 320 registers and only became resident when
 // the update's waves had drained from a SIMD: no gain.  CU-masked streams, which would have given it CUs of its own,
-// crash inside hipExtStreamCreateWithCUMask on this ROCm 7.2 / gfx950 stack, tools/cumask_probe.hip.)
+// crash inside hipExtStreamCreateWithCUMask on this ROCm 7.2 / gfx950 stack, tools/cumask_probe.hip.
+// Tried again with the four-wave k_big_potrf (104 registers, resident beside the update): the next column's tiles first on
+// st, the bulk on a side stream behind an event, st waiting for the bulk in front of its next update -- 18.4 ms per solve
+// against 18.6: the two event hand-overs per block column cost what the overlap of 29 us gains.)
 inline hipError_t big_solve_launch(hipStream_t st, int n, int n_upper, const long long *keys, const double *S, const double *g,
                                    double *x, double *A, double *Linv, int *info) {
     const int M = big_padded(n), nblk = M / BA_BIG_NB;
