@@ -165,6 +165,34 @@ def other_configs(_capi, synthetic):
                      "pcg_iterations_per_lm_step": s["pcg_iterations"] / max(s["iterations"], 1),
                      "cost": [s["initial_cost"], s["final_cost"]]}
     out["ring1778_loop"] = ring
+    # Object-centric capture: 1024 cameras around one object, every pair of cameras shares landmarks -- S is full, the
+    # "genuine dense contraction" of BASELINE.json's north_star: AUTO = blocked dense Cholesky on the fp64 matrix cores
+    # (ba_dense_big.h); block-Jacobi PCG forced beside it.  The flop rate charges the whole LM step minus the build pass
+    # (solve + back-substitution + step tail) with the n^3 / 3 of the factorisation: a lower bound for the solver.
+    p = synthetic.make_config("orbit1024")
+    n_unk = 6 * int((np.asarray(p["cam_fixed"]) == 0).sum())
+    orbit = {"cameras": len(p["cam_pose"]), "observations": len(p["obs_cam"]), "unknowns": n_unk,
+             "solver": "auto = blocked dense Cholesky (full block pattern); pcg_tol_1e-8 forces block-Jacobi PCG"}
+    for tag, kw in (("auto_dense_cholesky", {}), ("pcg_tol_1e-8", dict(linear_solver="pcg", pcg_tol=1e-8))):
+        with _capi.Handle(_capi.Arrays.from_dict(p), loss="huber", f_scale=1.0, max_iter=300, **kw) as h:
+            if "build_ms" not in orbit:
+                h.build_bench(1e-4, warmup=0, reps=3)
+                orbit["build_ms"], _ = h.build_bench(1e-4, warmup=0, reps=10)
+            h.run(1)
+            h.synchronize()
+            t0 = time.perf_counter()
+            s = h.run(6)
+            h.synchronize()
+            dt = time.perf_counter() - t0
+        steps = max(s["iterations"] - 1, 1)
+        orbit[tag] = {"lm_steps": steps, "lm_iters_per_sec": steps / dt, "lm_pcg_iterations": s["pcg_iterations"],
+                      "cost": [s["initial_cost"], s["final_cost"]]}
+        if not kw:
+            solve_s = dt / steps - orbit["build_ms"] * 1e-3
+            orbit[tag]["solve_ms_upper_bound"] = solve_s * 1e3
+            orbit[tag]["fp64_mfma_tflops_lower_bound"] = n_unk ** 3 / 3.0 / solve_s / 1e12
+            orbit[tag]["fp64_mfma_frac_of_78.6_lower_bound"] = n_unk ** 3 / 3.0 / solve_s / 78.6e12
+    out["orbit1024"] = orbit
     return out
 
 

@@ -197,6 +197,12 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// LDS written by some lanes of a wave and read by others of the SAME wave: wait for the LDS only, no barrier
+__device__ __forceinline__ void wave_lds_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // index of (i,j), i<=j, in a row-major packed upper triangle of a 6x6
 __host__ __device__ __forceinline__ constexpr int ut6(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }
 

@@ -99,6 +99,8 @@ constexpr int U_REPLICAS = 4;
 constexpr int U_REP_STRIDE = CHUNK_CAMS * 27 + 20;  // doubles; 776 = 16 banks (of 4 bytes) past a multiple of 64
 constexpr int P_REP_BASE = U_REPLICAS * U_REP_STRIDE + 6;  // second replica of the per-point sums, behind the camera replicas
 static_assert(P_REP_BASE + CHUNK_PTS * 9 <= CHUNK_OBS * 18, "the replicas live in the T buffer");
+constexpr int STG_WAVE = 8 * 36 + 16;  // doubles per wave behind the T rows: eight staged Schur blocks + 32 block slots (phase 3)
+static_assert(CHUNK_OBS * T_STRIDE + (CHUNK_OBS / 64) * STG_WAVE <= CHUNK_OBS * 18, "the staging area lives behind the T rows");
 // LOSS: the robust loss as a compile-time constant (huber, the only kind the reference uses), or -1 for A.loss (the
 // generic switch carries the polynomial constants of log1p / atan through the kernel's registers).
 template <bool STAMP, int LOSS>
@@ -406,17 +408,39 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
 #pragma unroll
             for (int k = 0; k < 36; ++k) acc[k] += dpp_f64<0xB1>(acc[k]);
             if (round > 0) {
+                // Straight to HBM, but not from the registers: a lane's atomics would go to 64 different blocks per wave
+                // instruction, 64 memory-side requests of 8 bytes each (unstructured visibility -- hardly two points of a
+                // chunk share a camera pair -- spends its time there).  Each wave turns its 32 blocks through a staging
+                // area behind the T rows, eight blocks at a time, and adds them with consecutive lanes on consecutive
+                // elements: one request per 64-byte line.
+                double *stg = &sT[CHUNK_OBS * T_STRIDE + (tid >> 6) * STG_WAVE];
+                int *stg_slot = reinterpret_cast<int *>(stg + 8 * 36);
+                const int lane = tid & 63, pl = lane >> 1;
                 // (the group's first entry sits in the EVEN lane; the odd lane has none when the group holds at most four)
-                const unsigned first = (unsigned)__builtin_amdgcn_update_dpp(0, (int)en[0], 0xA0, 0xf, 0xf, true);  // quad_perm [0,0,2,2]
-                if (first != PAIR_NULL) {
-                    double *d = &A.S[(size_t)A.ck_pair_slot[qb + (int)(first >> 16)] * 36];
-                    if (half == 0) {
+                if (half == 0) stg_slot[pl] = en[0] != PAIR_NULL ? A.ck_pair_slot[qb + (int)(en[0] >> 16)] : -1;
+#pragma unroll 1
+                for (int b = 0; b < 4; ++b) {
+                    if ((pl >> 3) == b) {
+                        double *d = &stg[(pl & 7) * 36];
+                        if (half == 0) {
 #pragma unroll
-                        for (int k = 0; k < 18; ++k) atomicAdd(&d[k], -acc[k]);
-                    } else {
+                            for (int k = 0; k < 18; ++k) d[k] = -acc[k];
+                        } else {
 #pragma unroll
-                        for (int k = 18; k < 36; ++k) atomicAdd(&d[k], -acc[k]);
+                            for (int k = 18; k < 36; ++k) d[k] = -acc[k];
+                        }
                     }
+                    wave_lds_sync();
+#pragma unroll 1
+                    for (int i = 0; i < 5; ++i) {
+                        const int e = lane + 64 * i;
+                        if (e < 8 * 36) {
+                            const int blk = e / 36, k = e - blk * 36;
+                            const int slot = stg_slot[8 * b + blk];
+                            if (slot >= 0) atomicAdd(&A.S[(size_t)slot * 36 + k], stg[e]);
+                        }
+                    }
+                    wave_lds_sync();
                 }
             }
         }

@@ -161,6 +161,23 @@ def make_ring(n_cams, n_points, seed=0, K=(1520.4, 1525.9, 302.32, 246.87), foca
         else:
             start = np.clip(start, 0, n_cams - L)
             obs_cam = np.repeat(start, L) + within
+    elif visibility == "random":
+        # object-centric capture: every point is seen by a random set of cameras from all around the ring (mean length
+        # ``mean_track``) -- any two cameras share landmarks, the reduced camera system is (nearly) full
+        n_obs = int(round(mean_track * n_obs_pts))
+        L = _track_lengths(rng, n_obs_pts, n_obs, max_track=min(n_cams, max_track))
+        obs_pt = np.repeat(np.arange(n_obs_pts, dtype=np.int64), L)
+        obs_cam = rng.integers(0, n_cams, size=len(obs_pt))
+        key = np.unique(obs_pt * n_cams + obs_cam)        # (a camera drawn twice for one point counts once)
+        obs_pt, obs_cam = key // n_cams, key % n_cams
+        cnt = np.bincount(obs_pt, minlength=n_obs_pts)
+        lone = np.flatnonzero(cnt < 2)                      # keep every track at two observations or more
+        if len(lone):
+            first_cam = np.zeros(n_obs_pts, np.int64); first_cam[obs_pt[::-1]] = obs_cam[::-1]
+            extra_cam = np.where(cnt[lone] == 0, 0, (first_cam[lone] + 1) % n_cams)
+            obs_pt = np.concatenate([obs_pt, lone]); obs_cam = np.concatenate([obs_cam, extra_cam])
+            zero = lone[cnt[lone] == 0]
+            obs_pt = np.concatenate([obs_pt, zero]); obs_cam = np.concatenate([obs_cam, np.ones(len(zero), np.int64)])
     elif visibility == "sfm":
         ns = n_obs_pts // 8 if n_seed_points is None else n_seed_points
         pt_a = np.arange(ns, dtype=np.int64)
@@ -199,11 +216,17 @@ def make_config(name, seed=None, scale=1.0):
                          noise=0.35, mean_track=4.0, n_fixed=1)
     if name == "ring1778_loop":
         # NOT banded: the Ladybug-sized camera count on a closed ring (camera 1777 sees what camera 0 sees: loop closure)
-        # with tracks of up to 40 cameras -- the reduced camera system has no small bandwidth in any camera order, so
-        # the solve goes through the block-Jacobi PCG (bench.py reports its LM iterations/s and PCG iterations)
+        # with tracks of up to 40 cameras -- not a chain in any camera order; AUTO solves it by cyclic reduction on the ring
+        # (bench.py reports LM iterations/s for that and for the block-Jacobi PCG forced on the same problem)
         return make_ring(1778, int(150000 * scale), seed=1239 if seed is None else seed, K=(1200.0, 1200.0, 960.0, 540.0),
                          focal_jitter=0.05, noise=0.5, outlier_frac=0.01, mean_track=8.0, max_track=40, n_fixed=2,
                          radius=283.0, point_radius=(4.0, 30.0), sig_t=2e-2, sig_p=5e-2)
+    if name == "orbit1024":
+        # object-centric: 1024 cameras around one object, every point seen from all around -- S is full (6132 unknowns):
+        # AUTO's blocked dense Cholesky (ba_dense_big.h), the "genuine dense contraction" of BASELINE.json's north_star
+        return make_ring(1024, int(120000 * scale), seed=1240 if seed is None else seed, K=(1200.0, 1200.0, 960.0, 540.0),
+                         focal_jitter=0.05, noise=0.5, outlier_frac=0.01, visibility="random", mean_track=8.0, max_track=24,
+                         n_fixed=2, radius=6.0)
     if name in SHAPES:
         nc, np_, no = SHAPES[name]
         idx = {"ladybug1723": 3, "venice1778": 4, "city10k": 5}[name]

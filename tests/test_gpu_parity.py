@@ -307,6 +307,46 @@ def test_blocked_dense_cholesky_at_ladybug_size(gpu):
     print("3 LM steps at 10326 unknowns: banded %.1f ms, blocked dense %.1f ms" % (sb["t_solve_ms"], sd["t_solve_ms"]))
 
 
+def test_unstructured_visibility_reduced_system(gpu):
+    """Random visibility (hardly two points of a chunk share a camera pair): most Schur groups lie beyond a chunk's first
+    round and leave through the per-wave staging area, many cameras have no LDS tile -- reduced system against the oracle."""
+    p = synthetic.make_ring(90, 1500, seed=78, K=(1200.0, 1200.0, 960.0, 540.0), focal_jitter=0.05, noise=0.5, outlier_frac=0.02,
+                            visibility="random", mean_track=7.0, max_track=20, n_fixed=2, radius=6.0)
+    arr = _capi.Arrays.from_dict(p)
+    a = _capi.analyze(arr)
+    assert a["n_direct_pairs"] > 1000 and a["n_direct_cam_obs"] > 1000
+    lam = 1e-3
+    nb = O.normal_blocks(*oracle_args(p), p["obs_xy"], 1.0, "huber", floor=1.0)
+    S, gred, _, _, _ = O.reduced_system(nb, p["cam_fixed"], p["obs_cam"], p["obs_pt"], lam)
+    with _capi.Handle(arr, loss="huber", f_scale=1.0) as h:
+        h.build(lam)
+        r = h.reduced_system()
+        free = p["cam_fixed"] == 0
+        assert rel(r["U"][free], nb["U"][free]) < 1e-12 and rel(r["gc"][free], nb["gc"][free]) < 1e-11
+        assert rel(r["S"], S) < 1e-9 and rel(r["gred"], gred) < 1e-9
+        assert abs(h.cost() - nb["F"]) <= 1e-12 * nb["F"]
+
+
+def test_auto_takes_the_blocked_dense_solver_on_a_full_pattern(gpu):
+    """Object-centric capture (every point seen by a random set of the 300 cameras: 99 % of the blocks of S exist, 1788
+    unknowns): AUTO solves the reduced system with the blocked dense Cholesky -- no PCG iteration -- and follows the LM
+    path of block-Jacobi PCG at a tight inner tolerance to the same minimum (1e-6 relative, BASELINE.json)."""
+    p = synthetic.make_ring(300, 12000, seed=77, K=(1200.0, 1200.0, 960.0, 540.0), focal_jitter=0.05, noise=0.5, outlier_frac=0.01,
+                            visibility="random", mean_track=7.0, max_track=20, n_fixed=2, radius=6.0)
+    cnt = np.bincount(p["obs_pt"], minlength=len(p["points"]))
+    assert cnt.min() >= 2
+    a = _capi.analyze(_capi.Arrays.from_dict(p))
+    nf = int((p["cam_fixed"] == 0).sum())
+    assert a["nnz_blocks_full"] >= 0.9 * nf * nf          # (AUTO's rule: at least a quarter)
+    out = _lm_paths(p, ("auto", "pcg"), 150, pcg_tol=1e-10, pcg_max_iter=2000)
+    sa, sp = out["auto"][0], out["pcg"][0]
+    assert sa["pcg_iterations"] == 0 and sp["pcg_iterations"] > 0
+    assert sa["status"] > 0 and sp["status"] > 0
+    assert sa["final_cost"] < 0.2 * sa["initial_cost"]
+    assert abs(sa["final_cost"] - sp["final_cost"]) <= 1e-6 * sp["final_cost"]
+    np.testing.assert_allclose(out["auto"][1].cam_pose, out["pcg"][1].cam_pose, rtol=1e-4, atol=1e-5)
+
+
 def _lm_paths(p, solvers, max_iter, **kw):
     out = {}
     for solver in solvers:
