@@ -99,6 +99,7 @@ constexpr int U_REPLICAS = 4;
 constexpr int U_REP_STRIDE = CHUNK_CAMS * 27 + 20;  // doubles; 776 = 16 banks (of 4 bytes) past a multiple of 64
 constexpr int P_REP_BASE = U_REPLICAS * U_REP_STRIDE + 6;  // second replica of the per-point sums, behind the camera replicas
 static_assert(P_REP_BASE + CHUNK_PTS * 9 <= CHUNK_OBS * 18, "the replicas live in the T buffer");
+static_assert(CHUNK_CAMS_WIDE * 27 <= P_REP_BASE, "a wide chunk's single replicas end in front of the point replicas");
 constexpr int STG_WAVE = 8 * 36 + 16;  // doubles per wave behind the T rows: eight staged Schur blocks + 32 block slots (phase 3)
 static_assert(CHUNK_OBS * T_STRIDE + (CHUNK_OBS / 64) * STG_WAVE <= CHUNK_OBS * 18, "the staging area lives behind the T rows");
 // LOSS: the robust loss as a compile-time constant (huber, the only kind the reference uses), or -1 for A.loss (the
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
     __shared__ __attribute__((aligned(16))) double sP[CHUNK_PTS * 9];    // per point: V(6) g_p(3), then L^-1(6) u(3)
     __shared__ __attribute__((aligned(16))) double sC[CHUNK_CAMS * 33];  // per local camera: U(21) g_c(6) g_red part(6)
     __shared__ double sRed[8];
-    __shared__ int sCam[CHUNK_CAMS];                                     // free-camera index of each local camera
+    __shared__ int sCam[CHUNK_CAMS_WIDE];                                // free-camera index of each local camera
     __shared__ unsigned char sLp[CHUNK_OBS];                             // local point of each observation
     __shared__ unsigned char sLc[CHUNK_OBS];                             // local camera of each observation
     __shared__ int sPg[CHUNK_OBS / 2 + 2], sSlot[CHUNK_OBS / 2 + 1];    // group offsets / S block slots of the first pairs
@@ -123,6 +124,12 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
     const int cb = A.ck_cam[ck], ncam = A.ck_cam[ck + 1] - cb;
     const int qb = A.ck_pair[ck], npair = A.ck_pair[ck + 1] - qb;
     const double lam = A.state->lambda;
+    // A "wide" chunk has more cameras than full tiles (unstructured visibility: a new camera with nearly every
+    // observation): ONE replica per camera at sT[slot * 27], and the cameras from slot CHUNK_CAMS on have no tile in sC --
+    // their U, g_c leave for HBM right after phase 1 (consecutive lanes on consecutive elements), their part of the reduced
+    // gradient goes the way of the cameras without any slot (phase 2b).
+    const bool wide = ncam > CHUNK_CAMS;
+    const int ntile = wide ? CHUNK_CAMS : ncam;
 
     BA_STAMP(0);
     // All global loads of the chunk are issued here, unconditionally (clamped indices: a branch around a load makes
@@ -156,11 +163,15 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
     const double X0 = A.points[3 * (size_t)p], X1 = A.points[3 * (size_t)p + 1], X2 = A.points[3 * (size_t)p + 2];
     const double floor_now = A.state->floor;
     for (int i = tid; i < npts * 9; i += CHUNK_OBS) sP[i] = 0.0;
-    for (int i = tid; i < ncam * 33; i += CHUNK_OBS) sC[i] = 0.0;
+    for (int i = tid; i < ntile * 33; i += CHUNK_OBS) sC[i] = 0.0;
     // four replicas of the cameras' U / g_c tiles in the T buffer, which is idle until phase 2b (see phase 1)
-    for (int i = tid; i < ncam * 27; i += CHUNK_OBS) {
+    if (!wide) {
+        for (int i = tid; i < ncam * 27; i += CHUNK_OBS) {
 #pragma unroll
-        for (int r = 0; r < U_REPLICAS; ++r) sT[r * U_REP_STRIDE + i] = 0.0;
+            for (int r = 0; r < U_REPLICAS; ++r) sT[r * U_REP_STRIDE + i] = 0.0;
+        }
+    } else {
+        for (int i = tid; i < ncam * 27; i += CHUNK_OBS) sT[i] = 0.0;
     }
     for (int i = tid; i < npts * 9; i += CHUNK_OBS) sT[P_REP_BASE + i] = 0.0;  // second replica of the point sums
     if (tid < ncam) sCam[tid] = st_cam;
@@ -214,7 +225,8 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
                 // Same-address fp64 LDS atomics serialise (1.5 lane-ops per clock for this pattern against 8.6 for
                 // distinct addresses, tools/lds_bench.hip): the lanes of one camera are spread over four bank-shifted
                 // replicas of its tile by their point index (4.3 lane-ops per clock); summed after the barrier.
-                double *cp = &sT[(lp & (U_REPLICAS - 1)) * U_REP_STRIDE + lc * 27];
+                double *cp = &sT[(wide ? 0 : (lp & (U_REPLICAS - 1)) * U_REP_STRIDE) + lc * 27];
+                if (lc >= CHUNK_CAMS) fcam = sCam[lc];   // (phase 2b: its reduced gradient goes to HBM directly)
 #pragma unroll
                 for (int i = 0; i < 6; ++i) {
 #pragma unroll
@@ -245,12 +257,26 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
 
     BA_STAMP(3);
     // camera tiles = sum of their replicas (highest lanes first: the low lanes have a point each in phase 2a)
-    for (int item = CHUNK_OBS - 1 - tid; item < ncam * 27; item += CHUNK_OBS) {
-        const int l = item / 27;
-        double v = 0.0;
+    if (!wide) {
+        for (int item = CHUNK_OBS - 1 - tid; item < ncam * 27; item += CHUNK_OBS) {
+            const int l = item / 27;
+            double v = 0.0;
 #pragma unroll
-        for (int r = 0; r < U_REPLICAS; ++r) v += sT[r * U_REP_STRIDE + item];
-        sC[l * 33 + (item - l * 27)] = v;
+            for (int r = 0; r < U_REPLICAS; ++r) v += sT[r * U_REP_STRIDE + item];
+            sC[l * 33 + (item - l * 27)] = v;
+        }
+    } else {
+        for (int item = CHUNK_OBS - 1 - tid; item < ncam * 27; item += CHUNK_OBS) {
+            const int l = item / 27, k = item - l * 27;
+            const double v = sT[item];
+            if (l < CHUNK_CAMS) {
+                sC[l * 33 + k] = v;
+            } else {
+                const size_t f = (size_t)sCam[l];
+                if (k < 21) atomicAdd(&A.U[f * 21 + k], v);
+                else atomicAdd(&A.gc[f * 6 + (k - 21)], v);
+            }
+        }
     }
     BA_STAMP(4);
     // ---- phase 2a: one point per lane: damp, 3x3 Cholesky, inverse factor in registers ------
@@ -317,7 +343,7 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
 #pragma unroll
         for (int k = 0; k < 9; ++k) tp[k] = t[k];
         tp[9] = Yr[0]; tp[10] = Yr[1]; tp[11] = Yr[2];
-        if (lc == -1) {  // camera without a tile: its part of the reduced gradient, -T u = -[Y x w; w], w = T' u
+        if (lc == -1 || lc >= CHUNK_CAMS) {  // camera without a tile: its part of the reduced gradient, -T u = -[Y x w; w], w = T' u
             const double u0 = vp[6], u1 = vp[7], u2 = vp[8];
             const double w0 = t[0] * u0 + t[1] * u1 + t[2] * u2, w1 = t[3] * u0 + t[4] * u1 + t[5] * u2,
                          w2 = t[6] * u0 + t[7] * u1 + t[8] * u2;
@@ -458,7 +484,7 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
 
     BA_STAMP(9);
     // ---- phase 4: one flush per chunk (fp64 atomics to HBM) ------------------------------------------
-    for (int i = tid; i < ncam * 33; i += CHUNK_OBS) {
+    for (int i = tid; i < ntile * 33; i += CHUNK_OBS) {
         const int l = i / 33, k = i - l * 33;
         const size_t f = (size_t)sCam[l];
         const double v = sC[i];

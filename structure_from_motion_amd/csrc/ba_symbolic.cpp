@@ -154,7 +154,7 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
         std::vector<int32_t> cam_stamp(std::max(s.n_free, 1), -1), cam_slot(std::max(s.n_free, 1), 0);
         // local pair ids of the open chunk: a (slot, slot) table for cameras with an LDS slot, a hash map for the rest
         std::unordered_map<int64_t, int32_t> pair_map;
-        std::vector<int32_t> pair_lut((size_t)CHUNK_CAMS * CHUNK_CAMS, -1), lut_touched;
+        std::vector<int32_t> pair_lut((size_t)CHUNK_CAMS_WIDE * CHUNK_CAMS_WIDE, -1), lut_touched;
         std::vector<int32_t> pair_cnt;  // entries per local pair of the open chunk
         std::vector<uint32_t> sorted;   // scratch of close_chunk
         std::vector<int32_t> pair_off;
@@ -162,7 +162,7 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
         auto find_pair = [&](int fa, int fc, int chunk_now) -> int32_t {
             if (cam_stamp[fa] != chunk_now || cam_stamp[fc] != chunk_now) return -1;
             const int sa = cam_slot[fa], sc = cam_slot[fc];
-            if (sa >= 0 && sc >= 0) return pair_lut[(size_t)sa * CHUNK_CAMS + sc];
+            if (sa >= 0 && sc >= 0) return pair_lut[(size_t)sa * CHUNK_CAMS_WIDE + sc];
             auto it = pair_map.find(((int64_t)fa << 32) | (uint32_t)fc);
             return it == pair_map.end() ? -1 : it->second;
         };
@@ -272,7 +272,7 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
                 if (f >= 0) {
                     if (cam_stamp[f] != chunk) {
                         cam_stamp[f] = chunk;
-                        if (cur_cams < CHUNK_CAMS) {
+                        if (cur_cams < CHUNK_CAMS_WIDE) {
                             cam_slot[f] = cur_cams++;
                             P.ck_cam_list.push_back(f);
                         } else {
@@ -297,8 +297,8 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
                         const int64_t key = ((int64_t)fidx[a] << 32) | (uint32_t)fidx[c];
                         const int sa = cam_slot[fidx[a]], sc = cam_slot[fidx[c]];
                         if (sa >= 0 && sc >= 0) {
-                            pair_lut[(size_t)sa * CHUNK_CAMS + sc] = lp;
-                            lut_touched.push_back(sa * CHUNK_CAMS + sc);
+                            pair_lut[(size_t)sa * CHUNK_CAMS_WIDE + sc] = lp;
+                            lut_touched.push_back(sa * CHUNK_CAMS_WIDE + sc);
                         } else {
                             pair_map.emplace(key, lp);
                         }

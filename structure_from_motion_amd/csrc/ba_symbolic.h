@@ -17,7 +17,9 @@ namespace ba {
 
 constexpr int CHUNK_OBS = 256;   // observations per chunk = threads per workgroup
 constexpr int CHUNK_PTS = 100;   // points per chunk (LDS slots)
-constexpr int CHUNK_CAMS = 28;   // cameras with an LDS tile per chunk
+constexpr int CHUNK_CAMS = 28;   // cameras with a full LDS tile per chunk (U, g_c in four replicas, reduced gradient)
+constexpr int CHUNK_CAMS_WIDE = 112;  // local camera slots per chunk: a chunk with more than CHUNK_CAMS cameras is "wide" -- one
+                                      // replica per camera, and the cameras from slot CHUNK_CAMS on flush U, g_c right after phase 1
 constexpr int PAIR_RUN = 8;      // pair entries per group = per lane pair of the build kernel (see Symbolic::pair_entries)
 constexpr uint32_t PAIR_NULL = 0xFFFFFFFFu;  // padding entry (local pair ids stay below 0xFFFF: at most 256 * 257 / 2 pairs)
 
@@ -40,7 +42,7 @@ struct Symbolic {
     std::vector<int64_t> obs_order;  // internal observation -> caller's observation index
     std::vector<int32_t> o_cam;      // [n_obs] camera index, internal order
     std::vector<int32_t> o_pt;       // [n_obs] internal point index
-    std::vector<int16_t> o_lcam;     // [n_obs] chunk-local camera slot, -1 = no LDS tile (fixed cameras: -2)
+    std::vector<int16_t> o_lcam;     // [n_obs] chunk-local camera slot (< CHUNK_CAMS_WIDE), -1 = none (fixed cameras: -2)
     // chunks
     std::vector<int32_t> ck_obs;     // [n_chunks+1]
     std::vector<int32_t> ck_pt;      // [n_chunks+1] (internal point range)

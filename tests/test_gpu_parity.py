@@ -309,12 +309,13 @@ def test_blocked_dense_cholesky_at_ladybug_size(gpu):
 
 def test_unstructured_visibility_reduced_system(gpu):
     """Random visibility (hardly two points of a chunk share a camera pair): most Schur groups lie beyond a chunk's first
-    round and leave through the per-wave staging area, many cameras have no LDS tile -- reduced system against the oracle."""
+    round and leave through the per-wave staging area, the chunks are "wide" (more cameras than full LDS tiles: one replica
+    each, U and g_c flushed right after phase 1) -- reduced system against the oracle."""
     p = synthetic.make_ring(90, 1500, seed=78, K=(1200.0, 1200.0, 960.0, 540.0), focal_jitter=0.05, noise=0.5, outlier_frac=0.02,
                             visibility="random", mean_track=7.0, max_track=20, n_fixed=2, radius=6.0)
     arr = _capi.Arrays.from_dict(p)
     a = _capi.analyze(arr)
-    assert a["n_direct_pairs"] > 1000 and a["n_direct_cam_obs"] > 1000
+    assert a["n_direct_pairs"] > 1000 and a["max_chunk_cams"] > 28        # ("wide" chunks: cameras beyond the 28 full tiles)
     lam = 1e-3
     nb = O.normal_blocks(*oracle_args(p), p["obs_xy"], 1.0, "huber", floor=1.0)
     S, gred, _, _, _ = O.reduced_system(nb, p["cam_fixed"], p["obs_cam"], p["obs_pt"], lam)
@@ -325,6 +326,21 @@ def test_unstructured_visibility_reduced_system(gpu):
         assert rel(r["U"][free], nb["U"][free]) < 1e-12 and rel(r["gc"][free], nb["gc"][free]) < 1e-11
         assert rel(r["S"], S) < 1e-9 and rel(r["gred"], gred) < 1e-9
         assert abs(h.cost() - nb["F"]) <= 1e-12 * nb["F"]
+    # tracks of more than 112 cameras (but not "heavy"): more cameras in a chunk than it has slots of any kind -- the
+    # observations of the cameras without a slot add their camera sums to HBM one by one
+    p = synthetic.make_ring(400, 40, seed=79, K=(1200.0, 1200.0, 960.0, 540.0), focal_jitter=0.05, noise=0.5, visibility="random",
+                            mean_track=150.0, max_track=190, n_fixed=2, radius=6.0)
+    arr = _capi.Arrays.from_dict(p)
+    a = _capi.analyze(arr)
+    assert a["n_direct_cam_obs"] > 100 and a["n_heavy_points"] == 0 and a["max_chunk_cams"] == 112
+    nb = O.normal_blocks(*oracle_args(p), p["obs_xy"], 1.0, "huber", floor=1.0)
+    S, gred, _, _, _ = O.reduced_system(nb, p["cam_fixed"], p["obs_cam"], p["obs_pt"], lam)
+    with _capi.Handle(arr, loss="huber", f_scale=1.0) as h:
+        h.build(lam)
+        r = h.reduced_system()
+        free = p["cam_fixed"] == 0
+        assert rel(r["U"][free], nb["U"][free]) < 1e-12 and rel(r["gc"][free], nb["gc"][free]) < 1e-11
+        assert rel(r["S"], S) < 1e-9 and rel(r["gred"], gred) < 1e-9
 
 
 def test_auto_takes_the_blocked_dense_solver_on_a_full_pattern(gpu):
@@ -621,14 +637,14 @@ def test_append_replans_the_cyclic_reduction(gpu):
 
 def test_heavy_points_and_slotless_cameras(gpu):
     """Tracks longer than a chunk (3 landmarks seen by all 270 cameras: heavy-point kernels) next to windows of up to
-    60 cameras (more than a chunk has LDS camera tiles: the slot-less path), 5 % outliers: reduced system against the
+    60 cameras (more than a chunk has full LDS camera tiles: "wide" chunks), 5 % outliers: reduced system against the
     oracle, then the LM trajectory against the oracle's (the curvature floor drops below 1 on the way, so gradient
     and curvature weights differ)."""
     p = synthetic.make_ring(270, 110, seed=3, mean_track=30.0, max_track=60, n_landmarks=3, outlier_frac=0.05, n_fixed=2,
                             n_unobserved=2)
     arr = _capi.Arrays.from_dict(p)
     a = _capi.analyze(arr)
-    assert a["n_heavy_points"] == 3 and a["max_track"] == 270 and a["n_direct_cam_obs"] > 0
+    assert a["n_heavy_points"] == 3 and a["max_track"] == 270 and a["max_chunk_cams"] > 28   # (wide chunks)
     lam = 1e-3
     nb = O.normal_blocks(*oracle_args(p), p["obs_xy"], 1.0, "huber", floor=1.0)
     S, gred, _, _, _ = O.reduced_system(nb, p["cam_fixed"], p["obs_cam"], p["obs_pt"], lam)
