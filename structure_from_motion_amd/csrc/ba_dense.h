@@ -1,6 +1,6 @@
 // Dense fp64 Cholesky solve of the reduced camera system for SMALL camera counts
 // (6 * free cameras <= BA_DENSE_MAX: the reference's own workloads -- 9 to 46 free cameras).
-// One workgroup, blocked right-looking factorisation (32x32 diagonal blocks factored by one wave in LDS, trailing
+// One workgroup, blocked right-looking factorisation (32x32 diagonal blocks factored by one wave, trailing
 // update on the fp64 matrix cores) with the forward substitution fused in, then the backward substitution.  Larger systems use the banded
 // Cholesky or the block-Jacobi PCG (block-sparse S); a multi-workgroup factorisation for 10k-unknown dense systems is
 // not written.
@@ -11,6 +11,7 @@
 
 #include "ba_device.h"
 #include "ba_banded.h"  // band_wave_sync
+#include "ba_tile16.h"  // bcr_potrf16
 
 #define BA_DENSE_MAX 768
 #define BA_NB 32
@@ -48,8 +49,8 @@ __global__ void k_dense_assemble(int n_upper, const long long *__restrict__ keys
 
 // x = -A^{-1} g by Cholesky; A (row-major, lower triangle used) is overwritten by its lower factor.  info = 0 or the
 // 1-based index of the first non-positive pivot (then x is not valid).  One workgroup of 8 waves, blocked right-looking:
-//   1. the 32x32 diagonal block is factored by ONE wave in LDS (two lanes per row, four columns per step, wave-level
-//      synchronisation only), overlapped with the trailing update of the column before (look-ahead),
+//   1. the 32x32 diagonal block is factored by ONE wave as two 16x16 tiles (ba_tile16.h: rows in registers, readlane
+//      broadcasts, MFMA for the tile below and its update), overlapped with the trailing update of the column before (look-ahead),
 //   2. the panel below it: one row per lane, row <- row L_kk^-T with the inverse diagonal (no divides),
 //   3. the trailing update: every wave takes 32x32 blocks of the lower triangle as 2x2 fp64 MFMA tiles (16x16x4), operands
 //      read from the panel's copy in LDS (or in L2 when it does not fit),
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(BA_DENSE_THREADS) void k_dense_cholesky_solve(int n
     // row update below reads a fixed number of entries per lane at constant offsets, some of them past the diagonal.)
     __shared__ double sLd[2][BA_NB + 1][BA_NB + 1];
     __shared__ double sInvd[2][BA_NB];           // 1 / diagonal of that block
-    __shared__ double sColL[4][2 * BA_NB];    // the two scaled columns of the block being factored (+ slack)
+    __shared__ double sTileInv[16 * 17];      // inverse of the factor of the 16x16 tile just factored (diagonal block, wave 0)
     __shared__ double sY[BA_DENSE_MAX];
     __shared__ double sInvAll[BA_DENSE_MAX];     // 1 / diagonal of L, kept for the backward substitution
     __shared__ int sBad;
@@ -76,9 +77,9 @@ __global__ __launch_bounds__(BA_DENSE_THREADS) void k_dense_cholesky_solve(int n
     long long dt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime();
 #endif
 
-    // ---- 1. diagonal block (wave 0 only): wave 0 factors it in LDS; lanes r and r + 32 share row r (alternate columns), wave-level
-    // synchronisation only.  (A register-resident row per lane would be the natural form, but the compiler turns the
-    // 32 x 32 unrolled triangle into ~370 spilled registers.)
+    // ---- 1. diagonal block (wave 0 only): staged in LDS (lanes r and r + 32 share the loads of row r), factored as two
+    // 16x16 tiles with the rows in registers, wave-level synchronisation only.  (A register-resident row of 32 per lane
+    // turns into ~370 spilled registers; rows of 16 fit.)
     auto factor_diag = [&](const int kbx, const bool in_place) {
         const int k0 = kbx * BA_NB;
         const int kw = (n - k0 < BA_NB) ? n - k0 : BA_NB;
@@ -99,73 +100,35 @@ __global__ __launch_bounds__(BA_DENSE_THREADS) void k_dense_cholesky_solve(int n
         }
         band_wave_sync();
         int bad = 0;
-        // TWO columns per step (the step is bound by its LDS round trips and wave syncs, not by its width): the 2x2
-        // pivot block and this row's two entries in one round trip, the scaled columns to sColL (and into the block),
-        // sync, then the rank-2 update of the row in ONE batch -- all loads before the FMAs -- and sync
-        // FOUR columns per step (the step is bound by its LDS round trips and wave syncs, not by its width): the 4x4
-        // pivot block and this row's four entries in one round trip, every lane factors the pivot block redundantly and
-        // solves its row against it, the scaled columns go to sColL (and into the block), sync, then the rank-4 update of
-        // the row in batches of NT entries -- all loads of a batch before its FMAs -- and sync
-        auto update = [&](const int j, const double (&x)[4], const int first, auto nt) {
-            constexpr int NT = decltype(nt)::value;
-            // (one base address per array and constant offsets; entries past the diagonal are read -- inside the slack -- and dropped)
-            const int cb = j + 4 + hi + 2 * first;
-            const double *p0 = &sColL[0][cb], *p1 = &sColL[1][cb], *p2 = &sColL[2][cb], *p3 = &sColL[3][cb];
-            double *rp = &sL[0][0] + r * (BA_NB + 1) + cb;
-            const int lim = r - cb;
-            double c0[NT], c1[NT], c2[NT], c3[NT], rc[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                c0[t] = p0[2 * t];
-                c1[t] = p1[2 * t];
-                c2[t] = p2[2 * t];
-                c3[t] = p3[2 * t];
-                rc[t] = rp[2 * t];
-            }
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                if (2 * t <= lim) rp[2 * t] = fma(-x[3], c3[t], fma(-x[2], c2[t], fma(-x[1], c1[t], fma(-x[0], c0[t], rc[t]))));
-        };
-        for (int j = 0; j < BA_NB; j += 4) {
-            const double p00 = sL[j][j], p10 = sL[j + 1][j], p11 = sL[j + 1][j + 1], p20 = sL[j + 2][j], p21 = sL[j + 2][j + 1],
-                         p22 = sL[j + 2][j + 2], p30 = sL[j + 3][j], p31 = sL[j + 3][j + 1], p32 = sL[j + 3][j + 2], p33 = sL[j + 3][j + 3];
-            const double a0 = sL[r][j], a1 = sL[r][j + 1], a2 = sL[r][j + 2], a3 = sL[r][j + 3];
-            if (!(p00 > 0.0) && bad == 0) bad = k0 + j + 1;
-            const double rs0 = rsqrt_nr(p00 > 0.0 ? p00 : 1.0);
-            const double l10 = p10 * rs0, l20 = p20 * rs0, l30 = p30 * rs0;
-            const double e11 = p11 - l10 * l10;
-            if (!(e11 > 0.0) && bad == 0) bad = k0 + j + 2;
-            const double rs1 = rsqrt_nr(e11 > 0.0 ? e11 : 1.0);
-            const double l21 = (p21 - l20 * l10) * rs1, l31 = (p31 - l30 * l10) * rs1;
-            const double e22 = p22 - l20 * l20 - l21 * l21;
-            if (!(e22 > 0.0) && bad == 0) bad = k0 + j + 3;
-            const double rs2 = rsqrt_nr(e22 > 0.0 ? e22 : 1.0);
-            const double l32 = (p32 - l30 * l20 - l31 * l21) * rs2;
-            const double e33 = p33 - l30 * l30 - l31 * l31 - l32 * l32;
-            if (!(e33 > 0.0) && bad == 0) bad = k0 + j + 4;
-            const double rs3 = rsqrt_nr(e33 > 0.0 ? e33 : 1.0);
-            // this row against the pivot block (row j + k gets its diagonal entry; rows above it: 0)
-            double x[4];
-            x[0] = a0 * rs0;
-            x[1] = r > j ? (a1 - x[0] * l10) * rs1 : 0.0;
-            x[2] = r > j + 1 ? (a2 - x[0] * l20 - x[1] * l21) * rs2 : 0.0;
-            x[3] = r > j + 2 ? (a3 - x[0] * l30 - x[1] * l31 - x[2] * l32) * rs3 : 0.0;
-            if (hi == 0) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    sColL[k][r] = x[k];
-                    if (r >= j + k) sL[r][j + k] = x[k];      // (nobody reads these four columns of the block again here)
-                }
-            }
+        // Two 16x16 tiles (the tile chain of the cyclic reduction, ba_bcr.h): tile (0,0) factored and its factor inverted
+        // in registers, a row per lane, the pivot column's entries broadcast by readlane (bcr_potrf16); tile (1,0) <- (1,0)
+        // Linv^T and (1,1) -= (1,0) (1,0)^T on the matrix core; then tile (1,1).  13 k cycles per block -- the version
+        // before worked in LDS, four columns per step with every lane factoring the 4x4 pivot block redundantly: 31 k.
+        {
+            const int l15 = lane & 15, l4 = lane >> 4;
+            if (bcr_potrf16(&sL[l15][0], sTileInv, nullptr, lane)) bad = k0 + 1;
             band_wave_sync();
-            // row r, columns j+4 .. r: this lane takes c = j + 4 + hi + 2 t, t < (28 - j) / 2
-            if (j < 16) {
-                update(j, x, 0, std::integral_constant<int, 7>());
-                if (j < 12) update(j, x, 7, std::integral_constant<int, 7>());
-                else update(j, x, 7, std::integral_constant<int, 1>());
-            } else {
-                update(j, x, 0, std::integral_constant<int, 6>());
-            }
+            mfma_d4 w = mfma_d4{0.0, 0.0, 0.0, 0.0};
+            double aq[4], bq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { aq[q] = sL[16 + l15][4 * q + l4]; bq[q] = sTileInv[l15 * 17 + 4 * q + l4]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[q], bq[q], w, 0, 0, 0);
+            band_wave_sync();   // (every lane has read the old tile)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) sL[16 + l4 + 4 * v][l15] = w[v];
+            band_wave_sync();
+            mfma_d4 t;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) t[v] = sL[16 + l4 + 4 * v][16 + l15];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { aq[q] = -sL[16 + l15][4 * q + l4]; bq[q] = sL[16 + l15][4 * q + l4]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[q], bq[q], t, 0, 0, 0);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) sL[16 + l4 + 4 * v][16 + l15] = t[v];
+            band_wave_sync();
+            if (bcr_potrf16(&sL[16 + l15][16], sTileInv, nullptr, lane) && bad == 0) bad = k0 + 17;
             band_wave_sync();
         }
         if (hi == 0) {
