@@ -51,7 +51,8 @@ __global__ void k_dense_assemble(int n_upper, const long long *__restrict__ keys
 // 1-based index of the first non-positive pivot (then x is not valid).  One workgroup of 8 waves, blocked right-looking:
 //   1. the 32x32 diagonal block is factored by ONE wave as two 16x16 tiles (ba_tile16.h: rows in registers, readlane
 //      broadcasts, MFMA for the tile below and its update), overlapped with the trailing update of the column before (look-ahead),
-//   2. the panel below it: one row per lane, row <- row L_kk^-T with the inverse diagonal (no divides),
+//   2. the panel below it: P <- P X^T with X = L_kk^-1 (from the two tile inverses) on the matrix core, a strip of 16
+//      rows per wave,
 //   3. the trailing update: every wave takes 32x32 blocks of the lower triangle as 2x2 fp64 MFMA tiles (16x16x4), operands
 //      read from the panel's copy in LDS (or in L2 when it does not fit),
 // the forward substitution rides along in the trailing phase (wave 1, panel still in LDS); then the blocked backward
@@ -63,6 +64,7 @@ __global__ __launch_bounds__(BA_DENSE_THREADS) void k_dense_cholesky_solve(int n
     // row update below reads a fixed number of entries per lane at constant offsets, some of them past the diagonal.)
     __shared__ double sLd[2][BA_NB + 1][BA_NB + 1];
     __shared__ double sInvd[2][BA_NB];           // 1 / diagonal of that block
+    __shared__ double sX[BA_NB][BA_NB + 1];   // inverse of the factor of the current diagonal block (lower; the panel solve is a product with it)
     __shared__ double sTileInv[16 * 17];      // inverse of the factor of the 16x16 tile just factored (diagonal block, wave 0)
     __shared__ double sY[BA_DENSE_MAX];
     __shared__ double sInvAll[BA_DENSE_MAX];     // 1 / diagonal of L, kept for the backward substitution
@@ -108,6 +110,8 @@ __global__ __launch_bounds__(BA_DENSE_THREADS) void k_dense_cholesky_solve(int n
             const int l15 = lane & 15, l4 = lane >> 4;
             if (bcr_potrf16(&sL[l15][0], sTileInv, nullptr, lane)) bad = k0 + 1;
             band_wave_sync();
+#pragma unroll
+            for (int e = lane; e < 256; e += 64) sX[e >> 4][e & 15] = sTileInv[(e >> 4) * 17 + (e & 15)];   // X00
             mfma_d4 w = mfma_d4{0.0, 0.0, 0.0, 0.0};
             double aq[4], bq[4];
 #pragma unroll
@@ -129,6 +133,19 @@ __global__ __launch_bounds__(BA_DENSE_THREADS) void k_dense_cholesky_solve(int n
             for (int v = 0; v < 4; ++v) sL[16 + l4 + 4 * v][16 + l15] = t[v];
             band_wave_sync();
             if (bcr_potrf16(&sL[16 + l15][16], sTileInv, nullptr, lane) && bad == 0) bad = k0 + 17;
+            band_wave_sync();
+            // the inverse of the whole block for the panel product: X11, and X10 = -X11 (L10 X00) -- the accumulator of the
+            // inner product is the outer one's B operand as it stands (element q of a lane = row l4 + 4 q)
+#pragma unroll
+            for (int e = lane; e < 256; e += 64) sX[16 + (e >> 4)][16 + (e & 15)] = sTileInv[(e >> 4) * 17 + (e & 15)];
+            w = mfma_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w = __builtin_amdgcn_mfma_f64_16x16x4f64(sL[16 + l15][4 * q + l4], sX[4 * q + l4][l15], w, 0, 0, 0);
+            t = mfma_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t = __builtin_amdgcn_mfma_f64_16x16x4f64(-sTileInv[l15 * 17 + 4 * q + l4], w[q], t, 0, 0, 0);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) sX[16 + l4 + 4 * v][l15] = t[v];
             band_wave_sync();
         }
         if (hi == 0) {
@@ -169,72 +186,44 @@ __global__ __launch_bounds__(BA_DENSE_THREADS) void k_dense_cholesky_solve(int n
             }
             __syncthreads();
         }
-        for (int i = k0 + kw + tid; i < n; i += BA_DENSE_THREADS) {
-            double row[BA_NB];
-            double *ap = &A[(size_t)i * n + k0];
-            const int pr = i - (k0 + kw);
-            const bool staged = pr < srow;
-            if (staged) {
+        // P <- P X^T with X = L_kk^-1 (factor_diag): a product on the matrix core, one strip of 16 panel rows per wave and
+        // trip -- 12 MFMAs (X is lower triangular: three 16x16 tiles) in place of a 32-column substitution per row, whose
+        // serial FMA chain was 19 k cycles per block column at 276 unknowns.
+        {
+            const int l15 = lane & 15, l4 = lane >> 4;
+            const int nstrip = (prow + 15) >> 4;
+            for (int st = wave; st < nstrip; st += NW) {
+                const int pr0 = 16 * st;
+                const int pra = pr0 + l15 < prow ? pr0 + l15 : prow - 1;   // (rows past the end: a copy of the last one, not stored)
+                double aq[8];
+                if (pra < srow) {
 #pragma unroll
-                for (int c = 0; c < BA_NB; c += 2) {
-                    const double2 v = *reinterpret_cast<const double2 *>(&sPanel[pr * BA_PS + c]);
-                    row[c] = v.x;
-                    row[c + 1] = v.y;
+                    for (int q = 0; q < 8; ++q) aq[q] = sPanel[pra * BA_PS + 4 * q + l4];
+                } else {
+                    const double *ap = &A[(size_t)(k0 + kw + pra) * n + k0];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) aq[q] = ap[4 * q + l4];
                 }
-            } else {
+                mfma_d4 o0 = mfma_d4{0.0, 0.0, 0.0, 0.0}, o1 = mfma_d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int c = 0; c < BA_NB; ++c) row[c] = (c < kw) ? ap[c] : 0.0;
-            }
-            // Sub-blocks of eight columns: the 8x8 triangle in one LDS round trip, then the later columns lose the eight
-            // solved ones four columns at a time (independent 8-FMA chains).  The empty asm makes each group's address
-            // depend on the group before: left alone, the scheduler fetches all of L ahead and spills.
-            int z = 0;
+                for (int q = 0; q < 4; ++q) o0 = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[q], sX[l15][4 * q + l4], o0, 0, 0, 0);
 #pragma unroll
-            for (int b = 0; b < BA_NB / 8; ++b) {
-                const int c0 = 8 * b;
-                {
-                    double l[8][8];
+                for (int q = 0; q < 4; ++q) o1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[q], sX[16 + l15][4 * q + l4], o1, 0, 0, 0);
 #pragma unroll
-                    for (int i = 1; i < 8; ++i) {
-                        const double *lr = &sL[c0 + i][c0] + z;
+                for (int q = 0; q < 4; ++q) o1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[4 + q], sX[16 + l15][16 + 4 * q + l4], o1, 0, 0, 0);
+                band_wave_sync();   // (every lane holds its part of the strip before anyone overwrites it)
 #pragma unroll
-                        for (int k = 0; k < i; ++k) l[i][k] = lr[k];
+                for (int v = 0; v < 4; ++v) {
+                    const int pr = pr0 + l4 + 4 * v;
+                    if (pr < srow) {
+                        sPanel[pr * BA_PS + l15] = o0[v];
+                        sPanel[pr * BA_PS + 16 + l15] = o1[v];
+                    } else if (pr < prow) {
+                        double *ap = &A[(size_t)(k0 + kw + pr) * n + k0];
+                        ap[l15] = o0[v];
+                        ap[16 + l15] = o1[v];
                     }
-                    double iv[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) iv[i] = (&sInv[c0 + i])[z];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        double v = row[c0 + i];
-#pragma unroll
-                        for (int k = 0; k < i; ++k) v = fma(-row[c0 + k], l[i][k], v);
-                        row[c0 + i] = v * iv[i];
-                    }
-                    asm volatile("" : "+v"(z) : "v"(row[c0 + 7]));
                 }
-#pragma unroll
-                for (int cg = c0 + 8; cg < BA_NB; cg += 4) {
-                    double l[4][8];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const double *lr = &sL[cg + q][c0] + z;
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) l[q][k] = lr[k];
-                    }
-#pragma unroll
-                    for (int k = 0; k < 8; ++k)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) row[cg + q] = fma(-row[c0 + k], l[q][k], row[cg + q]);
-                    asm volatile("" : "+v"(z) : "v"(row[cg + 3]));
-                }
-            }
-            if (staged) {
-#pragma unroll
-                for (int c = 0; c < BA_NB; c += 2) *reinterpret_cast<double2 *>(&sPanel[pr * BA_PS + c]) = make_double2(row[c], row[c + 1]);
-            } else {
-#pragma unroll
-                for (int c = 0; c < BA_NB; ++c)
-                    if (c < kw) ap[c] = row[c];
             }
         }
         __syncthreads();
