@@ -52,6 +52,15 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
     std::vector<int32_t> cmin(n_points, INT32_MAX), cmax(n_points, -1);
     {
         int bad = 0;
+        if (n_obs < 200000) {   // one thread (parallel_for's own rule): plain updates, a third of the atomic pass's time
+            for (int64_t k = 0; k < n_obs; ++k) {
+                const int32_t c = obs_cam[k], p = obs_pt[k];
+                if (c < 0 || c >= n_cams || p < 0 || p >= n_points) { bad = 1; continue; }
+                ++cnt[p];
+                if (c < cmin[p]) cmin[p] = c;
+                if (c > cmax[p]) cmax[p] = c;
+            }
+        } else
         parallel_for(n_obs, [&](int64_t lo, int64_t hi) {
             for (int64_t k = lo; k < hi; ++k) {
                 const int32_t c = obs_cam[k], p = obs_pt[k];
@@ -112,6 +121,9 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
         // (scatter by point on host threads -- the order inside a point's run is settled by the sort that follows, whose
         // key (camera, caller's index) is total)
         std::vector<int64_t> fill(pstart.begin(), pstart.end() - 1);
+        if (n_obs < 200000) {
+            for (int64_t k = 0; k < n_obs; ++k) s.obs_order[fill[pt_inv[obs_pt[k]]]++] = k;
+        } else
         parallel_for(n_obs, [&](int64_t lo, int64_t hi) {
             for (int64_t k = lo; k < hi; ++k) s.obs_order[__atomic_fetch_add(&fill[pt_inv[obs_pt[k]]], (int64_t)1, __ATOMIC_RELAXED)] = k;
         });
