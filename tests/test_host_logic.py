@@ -254,3 +254,23 @@ def test_synthetic_shapes():
     assert len(t["cam_pose"]) == 47 and t["cam_fixed"].sum() == 1
     f = synthetic.make_config("fountain", scale=0.05)
     assert len(f["cam_pose"]) == 11 and f["cam_fixed"].sum() == 2
+
+
+def test_analyze_camera_slots_of_wide_chunks():
+    """Chunk-local camera slots (csrc/ba_symbolic.h): up to 28 cameras of a chunk get a full LDS tile, up to 112 a slot
+    ("wide" chunks: unstructured visibility), only the cameras beyond that add to HBM observation by observation."""
+    p = synthetic.make_street(60, 1500, 6000, seed=3, max_track=12)
+    a = _capi.analyze(_capi.Arrays.from_dict(p))
+    assert a["max_chunk_cams"] <= 28 and a["n_direct_cam_obs"] == 0
+    p = synthetic.make_ring(90, 1500, seed=78, visibility="random", mean_track=7.0, max_track=20, n_fixed=2, radius=6.0)
+    a = _capi.analyze(_capi.Arrays.from_dict(p))
+    assert 28 < a["max_chunk_cams"] <= 112 and a["n_direct_cam_obs"] == 0
+    free = p["cam_fixed"][p["obs_cam"]] == 0
+    cnt = np.bincount(p["obs_pt"][free], minlength=len(p["points"]))        # (pair entries: free cameras only)
+    assert a["n_pair_entries"] == int((cnt * (cnt + 1) // 2).sum())
+    p = synthetic.make_ring(400, 40, seed=79, visibility="random", mean_track=150.0, max_track=190, n_fixed=0, radius=6.0)
+    a = _capi.analyze(_capi.Arrays.from_dict(p))
+    cnt = np.bincount(p["obs_pt"], minlength=len(p["points"]))
+    assert a["max_chunk_cams"] == 112 and a["n_heavy_points"] == 0
+    assert a["n_direct_cam_obs"] == int(np.maximum(cnt - 112, 0).sum())     # (one point per chunk: its cameras past the 112th)
+    assert a["n_pair_entries"] == int((cnt * (cnt + 1) // 2).sum())
