@@ -78,13 +78,17 @@ def other_configs(_capi, synthetic):
     # module from the reference's containers (image_data tuples, point lists) = what Reconstruction.py:302-304 pays,
     # marshalling included; (3) the same through BASession (array marshalling, cached keypoints)
     p = synthetic.make_config("temple")
-    arr = _capi.Arrays.from_dict(p)
-    t0 = time.perf_counter()
-    s = _capi.solve(arr, loss="huber", f_scale=1.0, max_iter=300)
+    runs = []
+    for _rep in range(3):          # (best of three, as for the host-API entries below; the first call of a process also pays
+        arr = _capi.Arrays.from_dict(p)   # one-time costs: code objects, the page-locked staging buffer of the uploads)
+        t0 = time.perf_counter()
+        s = _capi.solve(arr, loss="huber", f_scale=1.0, max_iter=300)
+        runs.append(((time.perf_counter() - t0) * 1e3, s))
+    wall, s = min(runs, key=lambda r: r[0])
     out["temple_final_ba"] = {"cameras": len(p["cam_pose"]), "points": len(p["points"]), "observations": len(p["obs_cam"]),
                               "status": s["status"], "lm_steps": s["iterations"], "cost": [s["initial_cost"], s["final_cost"]],
                               "solve_ms": s["t_solve_ms"], "setup_ms": s["t_setup_ms"],
-                              "wall_ms_from_arrays": (time.perf_counter() - t0) * 1e3}
+                              "wall_ms_from_arrays": wall, "wall_ms_from_arrays_first_call": runs[0][0]}
     try:
         import contextlib
         import io

@@ -64,6 +64,64 @@ int fail(int code, const char *fmt, ...) {
 
 #define BA_MAX_WORLD 64  // ranks of one sharded solve
 
+// One-time uploads of small problems are bound by the call, not by the bytes: a blocking hipMemcpy from pageable memory
+// costs 20-35 us, and a handle is created with some thirty of them.  While a StageScope is open on the calling thread,
+// DevBuf::upload / refill copy their source into a process-wide page-locked staging buffer instead and enqueue a truly
+// asynchronous copy on the handle's stream; the scope's end synchronises the stream once (only then is the buffer handed
+// out again) and lets the buffer grow -- up to STAGE_MAX -- to what did not fit.  Large problems overflow it and take the
+// blocking path for the rest, where the call overhead does not matter.
+struct Stager {
+    std::mutex mu;
+    char *buf = nullptr;
+    size_t cap = 0, used = 0, missed = 0;
+    hipStream_t st = nullptr;   // the open scope's stream
+};
+constexpr size_t STAGE_MAX = (size_t)64 << 20, STAGE_FIRST = (size_t)8 << 20;   // (8 MB: the reference's own problem sizes)
+Stager g_stager;
+thread_local Stager *t_stage = nullptr;
+void *stage_take(size_t bytes) {
+    Stager *s = t_stage;
+    if (!s) return nullptr;
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (s->used + need > s->cap) {
+        s->missed += need;
+        return nullptr;
+    }
+    void *r = s->buf + s->used;
+    s->used += need;
+    return r;
+}
+struct StageScope {
+    hipStream_t st;
+    bool on = false;
+    explicit StageScope(hipStream_t stream) : st(stream) {
+        if (t_stage || getenv("BA_NO_STAGING")) return;   // (nested: the outer scope owns the buffer)
+        if (!g_stager.mu.try_lock()) return;   // (another thread is staging: this one takes the blocking copies)
+        g_stager.used = g_stager.missed = 0;
+        if (!g_stager.buf && hipHostMalloc((void **)&g_stager.buf, STAGE_FIRST, hipHostMallocPortable) == hipSuccess) g_stager.cap = STAGE_FIRST;
+        g_stager.st = stream;
+        t_stage = &g_stager;
+        on = true;
+    }
+    ~StageScope() {
+        if (!on) return;
+        (void)hipStreamSynchronize(st);   // every staged copy has left the buffer
+        Stager &g = g_stager;
+        if (g.missed > 0 && g.cap < STAGE_MAX) {
+            size_t want = g.used + g.missed + ((size_t)1 << 20);   // (geometric: a growing reconstruction re-allocates rarely)
+            if (want < 2 * g.cap) want = 2 * g.cap;
+            if (want > STAGE_MAX) want = STAGE_MAX;
+            if (g.buf) (void)hipHostFree(g.buf);
+            g.buf = nullptr;
+            g.cap = 0;
+            if (hipHostMalloc((void **)&g.buf, want, hipHostMallocPortable) == hipSuccess) g.cap = want;
+            else g.buf = nullptr;
+        }
+        t_stage = nullptr;
+        g.mu.unlock();
+    }
+};
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
@@ -119,19 +177,32 @@ struct DevBuf {
         }
         n = need;
         if (count == 0) return hipSuccess;
+        if (void *stg = stage_take(count * sizeof(T))) {
+            memcpy(stg, tail, count * sizeof(T));
+            return hipMemcpyAsync(p + keep, stg, count * sizeof(T), hipMemcpyHostToDevice, t_stage->st);
+        }
         return hipMemcpy(p + keep, tail, count * sizeof(T), hipMemcpyHostToDevice);
     }
     // (a BLOCKING copy: the sources of these one-time uploads are often temporaries that die before the stream is
     // synchronised, and HIP does not promise that a pageable-memory hipMemcpyAsync has read its source on return)
-    hipError_t upload(const std::vector<T> &v, hipStream_t) {
+    // -- unless a StageScope is open: then through the page-locked staging buffer, asynchronously on st
+    hipError_t upload(const std::vector<T> &v, hipStream_t st) {
         hipError_t e = alloc(v.size());
         if (e != hipSuccess || v.empty()) return e;
+        if (void *stg = stage_take(v.size() * sizeof(T))) {
+            memcpy(stg, v.data(), v.size() * sizeof(T));
+            return hipMemcpyAsync(p, stg, v.size() * sizeof(T), hipMemcpyHostToDevice, st);
+        }
         return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
     }
     // same as upload, but keeps the allocation when the size has not changed (ba_set_values)
     hipError_t refill(const std::vector<T> &v, hipStream_t s) {
         if (!p || n != v.size()) return upload(v, s);
         if (v.empty()) return hipSuccess;
+        if (void *stg = stage_take(v.size() * sizeof(T))) {
+            memcpy(stg, v.data(), v.size() * sizeof(T));
+            return hipMemcpyAsync(p, stg, v.size() * sizeof(T), hipMemcpyHostToDevice, s);
+        }
         return hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
     }
 };
@@ -857,6 +928,7 @@ int create_impl(const BaProblem *prob, const BaOptions *opt, BaHandle *h) {
     HostProblem hp;
     if ((e = fetch_problem(prob, hp, false))) return e;
     tick("fetch");
+    StageScope staging(h->stream);
     if ((e = build_structure(h, hp, prob->n_cams, prob->n_points, prob->n_obs))) return e;
     tick("structure + uploads");
     if ((e = upload_values(h, hp))) return e;
@@ -1081,6 +1153,7 @@ int ba_set_values(BaHandle *h, const BaProblem *prob, const BaOptions *opt) {
     }
     (void)hipSetDevice(h->device);
     HIPCHK(hipStreamSynchronize(h->stream));
+    StageScope staging(h->stream);
     HostProblem hp;
     try {
         if ((e = fetch_problem(prob, hp, false))) return e;
@@ -1120,6 +1193,7 @@ int ba_append(BaHandle *h, const BaProblem *grown, const BaOptions *opt, int32_t
     }
     (void)hipSetDevice(h->device);
     HIPCHK(hipStreamSynchronize(h->stream));
+    StageScope staging(h->stream);
     try {
         HostProblem hp;
         if ((e = fetch_problem(grown, hp, false))) return e;
