@@ -82,7 +82,8 @@ typedef struct BaOptions {
                               or in an order the planner finds from the co-visibility graph when the numbering is not
                               along the trajectory);
                               blocked dense Cholesky for a (nearly) full pattern up to 2048 free cameras; block-Jacobi
-                              PCG otherwise.  BANDED_CHOLESKY (chains, at most 16 apart) only on request */
+                              PCG otherwise.  BANDED_CHOLESKY (chains, at most 16 apart): on request, and under AUTO only
+                              for a chain that the cyclic reduction cannot plan (fewer than two blocks) */
     int32_t verbose;       /* 0 silent, 1 summary, 2 per-iteration table (<- verbose, :219) */
     int32_t device;        /* HIP device ordinal; -1 = current device */
     int32_t deterministic; /* reserved (0) */
@@ -158,6 +159,8 @@ int ba_eval_reprojection_errors_rt(const BaProblem *prob, const double *cam_rt, 
  *     host synchronisation; the result is in *out_cost_dev once the stream reaches that point;
  *   - the indices are never seen by the host, so they are checked on the device: an out-of-range obs_cam / obs_pt
  *     makes the result NaN (no fault);
+ *   - the FIRST call on a device looks the static array's address up (hipGetSymbolAddress, once per device): make one
+ *     call per device outside any graph capture before capturing calls;
  *   - every call on one GPU uses that GPU's one static array (about 4.4 MB per GPU, held until the process ends):
  *     calls that overlap on one GPU -- different streams or threads -- race on it.  Calls in stream order are fine. */
 int ba_eval_cost_noalloc(const BaProblem *prob, int32_t loss, double f_scale, double *out_cost_dev, void *stream);
@@ -212,7 +215,7 @@ int ba_build_bench(BaHandle *h, double lambda, int32_t warmup, int32_t reps, dou
  * (obs_cam, obs_pt) of the problem the handle was created from (checked; BA_ERR_INVALID otherwise); cam_pose,
  * cam_intr, points and obs_xy are uploaded again, opt (NULL = keep) replaces loss / tolerances / damping, and the
  * LM state starts afresh.  Skips the symbolic analysis, every allocation and the index uploads of ba_create: what
- * the reference's repeated inter_ba calls over an unchanged track set (sfm.py:184-191, 252-258) would re-pay. */
+ * the reference's repeated inter_ba calls over an unchanged track set (Reconstruction.py:253-255) would re-pay. */
 int ba_set_values(BaHandle *h, const BaProblem *prob, const BaOptions *opt);
 /* f1, the incremental driver's pattern (inter_ba every second image on a GROWING problem, Reconstruction.py:244-255,
  * marshalling BundleAdjustment.py:243-306): `grown` is the handle's problem with cameras, points and observations
@@ -224,7 +227,10 @@ int ba_set_values(BaHandle *h, const BaProblem *prob, const BaOptions *opt);
  *              re-allocated geometrically), old block slots keep their numbers.
  *   *mode = 0  rebuilt inside the handle: an old track grew, a long-track ("heavy") point is involved, or the prefix
  *              rule does not hold (e.g. the gauge changed at 15 images, BundleAdjustment.py:38).  Same result, full analysis.
- * Not for sharded handles (BA_ERR_UNSUPPORTED); a shrunken problem is BA_ERR_INVALID.  mode may be NULL. */
+ * Not for sharded handles (BA_ERR_UNSUPPORTED); a shrunken problem is BA_ERR_INVALID.  mode may be NULL.
+ * If the call fails after the structure has begun to change (out of memory, a HIP error), the handle is marked
+ * unusable: every other entry point returns BA_ERR_INVALID for it until a later ba_append succeeds (it then rebuilds
+ * the whole structure) or the handle is destroyed. */
 int ba_append(BaHandle *h, const BaProblem *grown, const BaOptions *opt, int32_t *mode);
 /* Up to max_steps LM trial steps (continues from the current state); fills *out. */
 int ba_run(BaHandle *h, int32_t max_steps, BaSummary *out);
@@ -235,7 +241,8 @@ int ba_get_cost(BaHandle *h, double *cost);
  * (nothing O(points) or O(observations) is marshalled or uploaded again).  Per camera, host pointers, both optional:
  * cam_rt [n_cams*12] = R (row-major), t exactly as the caller stores them (utils.py:273 multiplies by R as stored;
  * NULL = the handle's current poses), cam_k [n_cams*9] full K (NULL = from the handle's fx, fy, cx, cy).
- * out_err: host, [n_cams], NaN for cameras without observations. */
+ * out_err: host, [n_cams], NaN for cameras without observations.  Not for sharded handles (BA_ERR_UNSUPPORTED: a rank
+ * only holds its shard's observations). */
 int ba_get_reprojection_errors(BaHandle *h, const double *cam_rt, const double *cam_k, double *out_err);
 /* Parity probes (host pointers, any may be NULL): dense reduced system s[(6Nf)^2] row-major,
  * g_red[6Nf], per-camera u[n_cams*36] and g_c[n_cams*6], per-point v[n_points*9] (undamped)

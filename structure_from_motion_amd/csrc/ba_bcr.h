@@ -386,7 +386,10 @@ inline bool bcr_make_plan(int nf, const int64_t *keys, size_t nk, BcrPlan &P) {
     return true;
 }
 
-inline size_t bcr_matrix_doubles(const BcrPlan &P) { return (size_t)(P.m + P.n_slots) * P.nb * P.nb; }
+// m diagonal blocks D_k, the coupling slots, and m more blocks for the factors L_k: D_k stays READ-ONLY while a level is
+// being factored -- both workgroups of an eliminated block load it, and nothing orders the second one's load before
+// the first one's write-back (they may not even be resident together), so the factor goes to a block of its own
+inline size_t bcr_matrix_doubles(const BcrPlan &P) { return (size_t)(2 * P.m + P.n_slots) * P.nb * P.nb; }
 inline size_t bcr_vec_doubles(const BcrPlan &P) { return (size_t)P.m * P.nb; }
 inline size_t bcr_linv_doubles(const BcrPlan &P) { return (size_t)P.m * P.nt * 256; }
 #ifndef BA_BCR_BACK_THREADS
@@ -458,9 +461,10 @@ __device__ __forceinline__ void bcr_static_for(F &&f) {
     }
 }
 template <int NT>
-__global__ __launch_bounds__(64 * (NT + BA_BCR_DWAVES)) void k_bcr_factor(const BcrElim *__restrict__ elims, double *__restrict__ D,
-                                                                         double *__restrict__ G, double *__restrict__ bv,
-                                                                         double *__restrict__ Linv16, int *__restrict__ info) {
+__global__ __launch_bounds__(64 * (NT + BA_BCR_DWAVES)) void k_bcr_factor(const BcrElim *__restrict__ elims, const double *__restrict__ D,
+                                                                         double *__restrict__ Lf, double *__restrict__ G,
+                                                                         double *__restrict__ bv, double *__restrict__ Linv16,
+                                                                         int *__restrict__ info) {
     constexpr int NB = 16 * NT, LDD = NB + 1, NTHREADS = 64 * (NT + BA_BCR_DWAVES);
     extern __shared__ double bcr_smem[];
     double *sD = bcr_smem;                    // (NB + 1) x LDD: D_k, row NB = right-hand side
@@ -472,7 +476,7 @@ __global__ __launch_bounds__(64 * (NT + BA_BCR_DWAVES)) void k_bcr_factor(const 
     if (side == 1 && slot < 0) return;
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    double *Dk = D + (size_t)el.k * NB * NB;
+    const double *Dk = D + (size_t)el.k * NB * NB;
     for (int e = tid; e < NB * NB; e += NTHREADS) {
         const int r = e / NB, c = e - r * NB;
         sD[r * LDD + c] = Dk[e];
@@ -621,13 +625,16 @@ __global__ __launch_bounds__(64 * (NT + BA_BCR_DWAVES)) void k_bcr_factor(const 
             for (int v = 0; v < 4; ++v) Gs[(size_t)(sr * 16 + l4 + 4 * v) * NB + c * 16 + l15] = acc[c][v];
     }
     if (side == 0) {
+        // the factor goes to Lf, NOT back into D_k: the other workgroup of this block may still have to load D_k
+        double *Lk = Lf + (size_t)el.k * NB * NB;
         for (int e = tid; e < NB * NB; e += NTHREADS) {
             const int r = e / NB, c = e - r * NB;
-            if (c <= r) Dk[e] = sD[r * LDD + c];
+            if (c <= r) Lk[e] = sD[r * LDD + c];
         }
         for (int e = tid; e < NB; e += NTHREADS) bv[(size_t)el.k * NB + e] = sD[NB * LDD + e];
-        if (wv == 0 && lane == 0 && bad) atomicCAS(info, 0, el.k + 1);
     }
+    // (both sides factor the same D_k and meet the same pivots; either one may raise the flag)
+    if (wv == 0 && lane == 0 && bad) atomicCAS(info, 0, el.k + 1);
     BCR_STAMP(4 + 4 * NT);
 }
 
@@ -696,7 +703,7 @@ __global__ __launch_bounds__(64 * BA_BCR_UPD_WAVES) void k_bcr_update(int n_ops,
 
 // ------------------------------------------------------------------------------------------------ backward
 template <int NT>
-__global__ __launch_bounds__(BA_BCR_BACK_THREADS) void k_bcr_back(const BcrElim *__restrict__ elims, const double *__restrict__ D,
+__global__ __launch_bounds__(BA_BCR_BACK_THREADS) void k_bcr_back(const BcrElim *__restrict__ elims, const double *__restrict__ Lf,
                                                   const double *__restrict__ G, double *__restrict__ bv,
                                                   const double *__restrict__ Linv16, const int32_t *__restrict__ pos_f,
                                                   double *__restrict__ xout) {
@@ -714,7 +721,7 @@ __global__ __launch_bounds__(BA_BCR_BACK_THREADS) void k_bcr_back(const BcrElim 
     const double yk = tid < NB ? bv[(size_t)el.k * NB + tid] : 0.0;
     const int fcam = tid < 6 * (NB / 6) ? pos_f[el.k * (NB / 6) + tid / 6] : -1;   // the camera of unknown tid of this block
     {
-        const double *L = D + el.k * nb2, *li = Linv16 + (size_t)el.k * NT * 256;
+        const double *L = Lf + el.k * nb2, *li = Linv16 + (size_t)el.k * NT * 256;
         for (int e = tid; e < NB * NB; e += BA_BCR_BACK_THREADS) sL[e] = L[e];
         for (int e = tid; e < NT * 256; e += BA_BCR_BACK_THREADS) sLi[e] = li[e];
     }
@@ -779,7 +786,7 @@ struct BcrDev {
     const BcrElim *elims;
     const BcrOp *ops;
     const int32_t *src, *pos_f;
-    double *DG;      // bcr_matrix_doubles: m diagonal blocks, then the coupling slots
+    double *DG;      // bcr_matrix_doubles: m diagonal blocks, the coupling slots, then the m factors L_k
     double *bv;      // bcr_vec_doubles
     double *linv;    // bcr_linv_doubles
     int *info;
@@ -806,7 +813,7 @@ template <int NT>
 inline hipError_t bcr_solve_launch_t(hipStream_t st, const BcrPlan &P, const BcrDev &d, const double *S, const double *g, double *x) {
     constexpr int NB = 16 * NT;
     const size_t nb2 = (size_t)NB * NB;
-    double *D = d.DG, *G = d.DG + (size_t)P.m * nb2;
+    double *D = d.DG, *G = d.DG + (size_t)P.m * nb2, *Lf = G + (size_t)P.n_slots * nb2;
     {
         const int n_blocks = P.m + P.n_init_slots;
         const size_t n_el = (size_t)n_blocks * nb2;
@@ -818,14 +825,14 @@ inline hipError_t bcr_solve_launch_t(hipStream_t st, const BcrPlan &P, const Bcr
     const int nl = P.levels();
     for (int l = 0; l < nl; ++l) {
         const int ne_l = P.lvl_elim[l + 1] - P.lvl_elim[l], no_l = P.lvl_op[l + 1] - P.lvl_op[l];
-        hipLaunchKernelGGL(k_bcr_factor<NT>, dim3(2 * ne_l), dim3(64 * (NT + BA_BCR_DWAVES)), lds, st, d.elims + P.lvl_elim[l], D, G,
+        hipLaunchKernelGGL(k_bcr_factor<NT>, dim3(2 * ne_l), dim3(64 * (NT + BA_BCR_DWAVES)), lds, st, d.elims + P.lvl_elim[l], D, Lf, G,
                            d.bv, d.linv, d.info);
         if (no_l > 0)
             hipLaunchKernelGGL(k_bcr_update<NT>, dim3(8 * ((no_l * WGS + 7) / 8)), dim3(64 * BA_BCR_UPD_WAVES), 0, st, no_l, d.ops + P.lvl_op[l], D, G, d.bv);
     }
     for (int l = nl - 1; l >= 0; --l) {
         const int ne_l = P.lvl_elim[l + 1] - P.lvl_elim[l];
-        hipLaunchKernelGGL(k_bcr_back<NT>, dim3(ne_l), dim3(BA_BCR_BACK_THREADS), bcr_back_lds_bytes(NT), st, d.elims + P.lvl_elim[l], D, G, d.bv, d.linv, d.pos_f, x);
+        hipLaunchKernelGGL(k_bcr_back<NT>, dim3(ne_l), dim3(BA_BCR_BACK_THREADS), bcr_back_lds_bytes(NT), st, d.elims + P.lvl_elim[l], Lf, G, d.bv, d.linv, d.pos_f, x);
     }
     return hipGetLastError();
 }

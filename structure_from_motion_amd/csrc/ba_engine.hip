@@ -356,6 +356,7 @@ struct BaHandle {
     int total_pcg = 0;
     double initial_cost = NAN;
     bool built = false;
+    bool poisoned = false;   // a ba_append failed half way: the host structure and the device arrays may disagree
     double t_setup_ms = 0.0;
 
     ~BaHandle() {
@@ -1085,6 +1086,13 @@ int residual_sum(BaHandle *h, double *cost, double *rsum) {
     return BA_OK;
 }
 
+// every entry point that reads the handle's structure starts here
+int usable(BaHandle *h) {
+    if (!h) return fail(BA_ERR_INVALID, "null handle");
+    if (h->poisoned) return fail(BA_ERR_INVALID, "the handle is unusable after a failed ba_append: call ba_append again (it rebuilds) or ba_destroy");
+    return BA_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1137,7 +1145,7 @@ void ba_destroy(BaHandle *h) {
 }
 
 int ba_set_values(BaHandle *h, const BaProblem *prob, const BaOptions *opt) {
-    if (!h) return fail(BA_ERR_INVALID, "null handle");
+    if (int eu = usable(h)) return eu;
     const double t0 = now_ms();
     int e = validate(prob);
     if (e) return e;
@@ -1181,7 +1189,7 @@ int ba_append(BaHandle *h, const BaProblem *grown, const BaOptions *opt, int32_t
     int e = validate(grown);
     if (e) return e;
     Symbolic &s = h->sym;
-    if (grown->n_cams < s.n_cams || grown->n_points < s.n_points || grown->n_obs < s.n_obs)
+    if (!h->poisoned && (grown->n_cams < s.n_cams || grown->n_points < s.n_points || grown->n_obs < s.n_obs))
         return fail(BA_ERR_INVALID, "ba_append: the problem shrank (%d cameras, %d points, %lld observations against the handle's %d, %d, %lld)",
                     grown->n_cams, grown->n_points, (long long)grown->n_obs, s.n_cams, s.n_points, (long long)s.n_obs);
     if (h->coll) return fail(BA_ERR_UNSUPPORTED, "ba_append on a sharded handle (the ranks would have to agree on a new pattern)");
@@ -1199,17 +1207,24 @@ int ba_append(BaHandle *h, const BaProblem *grown, const BaOptions *opt, int32_t
         if ((e = fetch_problem(grown, hp, false))) return e;
         // the handle's problem must be a prefix of the grown one: same gauge for the old cameras, same (camera, point) for
         // every old observation
-        bool prefix = true;
+        bool prefix = !h->poisoned;
         for (int c = 0; c < s.n_cams && prefix; ++c) prefix = (hp.cam_fixed[c] != 0) == (s.cam_free[c] < 0);
         for (int64_t k = 0; k < s.n_obs && prefix; ++k) {
             const int64_t src = s.obs_order[k];
             prefix = hp.obs_cam[src] == s.o_cam[k] && hp.obs_pt[src] == s.pt_order[s.o_pt[k]];
         }
+        // From here on the handle's structure is being replaced: an error (or an exception) half way leaves the host
+        // tables ahead of the device arrays.  The flag makes every later call on the handle fail cleanly -- except
+        // another ba_append, which then rebuilds the whole structure -- instead of launching over inconsistent tables.
+        const bool was_poisoned = h->poisoned;
+        h->poisoned = true;
+        h->built = false;
         bool appended = false;
-        if (prefix && (e = append_tail(h, hp, grown->n_cams, grown->n_points, grown->n_obs, &appended))) return e;
+        if (prefix && !was_poisoned && (e = append_tail(h, hp, grown->n_cams, grown->n_points, grown->n_obs, &appended))) return e;
         if (!appended && (e = build_structure(h, hp, grown->n_cams, grown->n_points, grown->n_obs))) return e;
         h->opt = o;
         if ((e = upload_values(h, hp))) return e;
+        h->poisoned = false;
         if (mode) *mode = appended ? 1 : 0;
         h->t_setup_ms = now_ms() - t0;
         return BA_OK;
@@ -1273,6 +1288,7 @@ int ba_get_pattern(BaHandle *h, int32_t *out_pairs, int64_t capacity, int64_t *n
 
 int ba_set_pattern(BaHandle *h, const int32_t *pairs, int64_t n_pairs) {
     if (!h || (n_pairs > 0 && !pairs)) return fail(BA_ERR_INVALID, "null argument");
+    if (int eu = usable(h)) return eu;
     if (n_pairs < 0) return fail(BA_ERR_INVALID, "negative pair count");
     try {
         std::vector<int64_t> extra;
@@ -1360,7 +1376,7 @@ int ba_get_stream(BaHandle *h, void **stream) {
 }
 
 int ba_build(BaHandle *h, double lambda) {
-    if (!h) return fail(BA_ERR_INVALID, "null handle");
+    if (int eu = usable(h)) return eu;
     (void)hipSetDevice(h->device);
     int e = set_lambda(h, lambda);
     if (e) return e;
@@ -1369,6 +1385,7 @@ int ba_build(BaHandle *h, double lambda) {
 
 int ba_build_bench(BaHandle *h, double lambda, int32_t warmup, int32_t reps, double *ms_per_pass, double *ms_fused_kernel) {
     if (!h || reps <= 0) return fail(BA_ERR_INVALID, "bad argument");
+    if (int eu = usable(h)) return eu;
     (void)hipSetDevice(h->device);
     int e = set_lambda(h, lambda);
     if (e) return e;
@@ -1398,7 +1415,7 @@ int ba_build_bench(BaHandle *h, double lambda, int32_t warmup, int32_t reps, dou
 }
 
 int ba_run(BaHandle *h, int32_t max_steps, BaSummary *out) {
-    if (!h) return fail(BA_ERR_INVALID, "null handle");
+    if (int eu = usable(h)) return eu;
     (void)hipSetDevice(h->device);
     const double t0 = now_ms();
     int e;
@@ -1462,7 +1479,7 @@ int ba_run(BaHandle *h, int32_t max_steps, BaSummary *out) {
 }
 
 int ba_get_state(BaHandle *h, double *cam_pose, double *points) {
-    if (!h) return fail(BA_ERR_INVALID, "null handle");
+    if (int eu = usable(h)) return eu;
     (void)hipSetDevice(h->device);
     const Symbolic &s = h->sym;
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -1479,6 +1496,7 @@ int ba_get_state(BaHandle *h, double *cam_pose, double *points) {
 
 int ba_get_cost(BaHandle *h, double *cost) {
     if (!h || !cost) return fail(BA_ERR_INVALID, "null argument");
+    if (int eu = usable(h)) return eu;
     (void)hipSetDevice(h->device);
     double rs;
     return residual_sum(h, cost, &rs);
@@ -1486,6 +1504,7 @@ int ba_get_cost(BaHandle *h, double *cost) {
 
 int ba_get_reduced_blocks(BaHandle *h, int64_t *keys, double *blocks, int64_t capacity, int64_t *n_blocks) {
     if (!h || !n_blocks) return fail(BA_ERR_INVALID, "null argument");
+    if (int eu = usable(h)) return eu;
     (void)hipSetDevice(h->device);
     if (!h->built) return fail(BA_ERR_INVALID, "ba_build has not run");
     const Symbolic &s = h->sym;
@@ -1499,7 +1518,7 @@ int ba_get_reduced_blocks(BaHandle *h, int64_t *keys, double *blocks, int64_t ca
 }
 
 int ba_get_reduced_system(BaHandle *h, double *s_out, double *g_red, double *u, double *g_c, double *v, double *g_p) {
-    if (!h) return fail(BA_ERR_INVALID, "null handle");
+    if (int eu = usable(h)) return eu;
     (void)hipSetDevice(h->device);
     const Symbolic &s = h->sym;
     if ((v || g_p) && h->dbg_v.n == 0) {
@@ -1574,6 +1593,7 @@ int ba_get_reduced_system(BaHandle *h, double *s_out, double *g_red, double *u, 
 // 12 s_memtime values per chunk.  Used by tools/stamps.py to see where a chunk spends its cycles.
 int ba_debug_stamps(BaHandle *h, unsigned long long *out, long long capacity) {
     if (!h || !out) return fail(BA_ERR_INVALID, "null argument");
+    if (int eu = usable(h)) return eu;
     (void)hipSetDevice(h->device);
     if (capacity < (long long)h->n_chunks * 12) return fail(BA_ERR_INVALID, "stamp buffer too small");
     HIPCHK(h->stamps.alloc((size_t)h->n_chunks * 12));
@@ -1831,6 +1851,9 @@ int ba_eval_reprojection_errors_rt(const BaProblem *p, const double *cam_rt, con
 
 int ba_get_reprojection_errors(BaHandle *h, const double *cam_rt, const double *cam_k, double *out_err) {
     if (!h || !out_err) return fail(BA_ERR_INVALID, "null argument");
+    if (int eu = usable(h)) return eu;
+    // (a sharded handle only holds its own shard's observations: a per-camera mean over them is not the camera's mean)
+    if (h->coll) return fail(BA_ERR_UNSUPPORTED, "ba_get_reprojection_errors on a sharded handle (each rank holds only its shard's observations)");
     (void)hipSetDevice(h->device);
     const Symbolic &s = h->sym;
     const size_t nc = (size_t)s.n_cams;
@@ -1894,7 +1917,10 @@ int ba_eval_cost_noalloc(const BaProblem *p, int32_t loss, double f_scale, doubl
     // the array keeps the last call's contents: the flag must start at zero; aux and the partials are overwritten
     // for exactly the cameras / blocks this call reads
     HIPCHK(hipMemsetAsync(flag, 0, sizeof(int), st));
-    hipLaunchKernelGGL(k_cam_prep, dim3((p->n_cams + 63) / 64), dim3(64), 0, st, p->n_cams, (const double *)p->cam_pose, p->cam_intr, aux);
+    // (no cameras: nothing to prepare -- a grid of zero blocks is an invalid launch -- and k_eval_cost<true> flags every
+    // observation, so the result is NaN as the header promises)
+    if (p->n_cams > 0)
+        hipLaunchKernelGGL(k_cam_prep, dim3((p->n_cams + 63) / 64), dim3(64), 0, st, p->n_cams, (const double *)p->cam_pose, p->cam_intr, aux);
     hipLaunchKernelGGL(k_eval_cost<true>, dim3(nb), dim3(256), 0, st, (long long)p->n_obs, aux, (const double *)p->points, p->obs_cam,
                        p->obs_pt, p->obs_xy, loss, 1.0 / (f_scale * f_scale), 0.5 * f_scale * f_scale, bc, br, p->n_cams,
                        p->n_points, flag);

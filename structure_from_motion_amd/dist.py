@@ -57,13 +57,16 @@ def make_collective(group=None, stream=None):
         torch.cuda.current_stream().synchronize()
         return 0
 
+    # (torch's `src` is a GLOBAL rank: the group's first rank, which is rank 0 of the library's numbering)
+    src0 = dist.get_global_rank(group, 0) if group is not None else 0
+
     def _run(t, op):
         if op == _capi.REDUCE_SUM:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         elif op == _capi.REDUCE_MAX:
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         else:
-            dist.broadcast(t, src=0, group=group)
+            dist.broadcast(t, src=src0, group=group)
     coll.stream_ordered = ext is not None
     return coll
 
@@ -114,7 +117,8 @@ def create_sharded_handle(shard, rank, world, group=None, stream_ordered=True, f
             native = dist.get_backend(group) == "nccl"
         if native:
             box = [_capi.rccl_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0, group=group)
+            # (`rank` is the rank inside `group`; torch's `src` is a global rank)
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
             h.rccl_init(box[0], rank, world)
         else:
             coll = make_collective(group, h.stream() if stream_ordered else None)

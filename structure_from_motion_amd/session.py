@@ -58,9 +58,12 @@ class BASession:
                 else:
                     self.close()
             except _capi.BaError as e:
+                # Whatever went wrong, this handle is not kept: after BA_ERR_INVALID (another problem altogether) a new
+                # one is made below; after anything else (out of memory, a HIP error half way through an append) the
+                # error goes to the caller, and the next call starts from a fresh handle as well.
+                self.close()
                 if e.code != _capi.BA_ERR_INVALID:
                     raise
-                self.close()                             # another problem altogether: a new handle
         if self._handle is None:
             self._handle = _capi.Handle(arr, **opts)
         h = self._handle

@@ -24,6 +24,9 @@ def _engine_problem():
     from structure_from_motion_amd import synthetic
     if os.environ.get("BA_TEST_PROBLEM") == "street203":
         return synthetic.make_street(203, 5000, 22000, seed=51, outlier_frac=0.01), 25
+    if os.environ.get("BA_TEST_PROBLEM") == "city_20th":
+        # BASELINE.json config 5 at 1/20 of its points and observations, ALL of its 10 000 cameras (replicated on every rank)
+        return synthetic.make_street(10000, 1_000_000, 5_000_000, seed=1233 + 5), 3
     return synthetic.make_ring(16, 600, seed=8, mean_track=4.0, outlier_frac=0.02), 80
 
 

@@ -81,3 +81,24 @@ def test_rank_without_observations_stays_in_step(gpu, tmp_path):
         assert abs(float(r["cost0"]) - s["initial_cost"]) <= 1e-12 * s["initial_cost"]
         assert abs(float(r["rsum"]) - s["residual_sum"]) <= 1e-7 * max(1.0, abs(s["residual_sum"]))
     assert float(r0["cost"]) == float(r1["cost"]) and float(r0["rsum"]) == float(r1["rsum"])
+
+
+def test_two_ranks_with_ten_thousand_replicated_cameras(gpu, tmp_path, monkeypatch):
+    """BASELINE.json config 5 through the sharded path: all 10 000 cameras replicated on two gloo ranks, 1/20 of the
+    points and observations (1 M / 5 M) cut in two by dist.shard_points.  Three LM steps: every rank solves the all-reduced
+    reduced camera system with the 10 000-camera cyclic reduction (no PCG iteration); same steps, same cost and the same
+    cameras as the single handle."""
+    monkeypatch.setenv("BA_TEST_PROBLEM", "city_20th")
+    p = synthetic.make_street(10000, 1_000_000, 5_000_000, seed=1233 + 5)
+    with _capi.Handle(_capi.Arrays.from_dict(p), loss="huber", f_scale=1.0, max_iter=3) as h:
+        s = h.run()
+        cp, _ = h.state()
+    assert s["pcg_iterations"] == 0 and s["accepted"] >= 1
+    mp.spawn(engine_sharded_solve, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert int(r0["pcg"]) == 0 and int(r1["pcg"]) == 0
+    assert int(r0["iters"]) == int(r1["iters"]) == s["iterations"] and int(r0["status"]) == int(r1["status"]) == s["status"]
+    np.testing.assert_array_equal(r0["cp"], r1["cp"])
+    assert float(r0["cost"]) == float(r1["cost"])
+    assert abs(float(r0["cost"]) - s["final_cost"]) <= 1e-9 * s["final_cost"]
+    assert np.allclose(r0["cp"], cp, rtol=1e-6, atol=1e-7)

@@ -791,3 +791,61 @@ def test_full_size_bal_shapes(gpu, name):
     assert s["accepted"] >= 1 and s["final_cost"] < s["initial_cost"]
     f1 = O.residuals(cp, p["cam_intr"], pts, p["obs_cam"], p["obs_pt"], p["obs_xy"])
     assert abs(O.cost(f1, 1.0, "huber") - s["final_cost"]) <= 1e-10 * s["final_cost"]
+
+
+def test_city_shard_10k_cameras(gpu):
+    """BASELINE.json config 5 (10 000 cameras, 20 M points, 100 M observations over 8 GPUs): the shard ONE rank of the
+    8-way run holds -- 2.5 M points / 12.5 M observations against all 10 000 replicated cameras, generated exactly as
+    bench.py --workload city10k does for rank 0 of 8 -- against the vectorised oracle: cost, U, g_c, V, g_p, reduced
+    gradient and the reduced camera system through S v; then three LM steps through AUTO, whose linear solver for 10 000
+    cameras on a street is the block cyclic reduction (no PCG iteration)."""
+    nc, n_pts, n_obs = synthetic.SHAPES["city10k"]
+    p = synthetic.make_street(nc, n_pts // 8, n_obs // 8, seed=1233 + 5, cam_seed=1233 + 5)
+    assert len(p["cam_pose"]) == 10000 and len(p["obs_cam"]) == 12_500_000
+    arr = _capi.Arrays.from_dict(p)
+    nb = O.normal_blocks(*oracle_args(p), p["obs_xy"], 1.0, "huber", floor=1.0)
+    lam = 1e-4
+    free = p["cam_fixed"] == 0
+    v = np.random.default_rng(2).normal(size=6 * int(free.sum()))
+    Sv, gred = O.reduced_matvec(nb, p["cam_fixed"], p["obs_cam"], p["obs_pt"], lam, v)
+    with _capi.Handle(arr, loss="huber", f_scale=1.0) as h:
+        h.build(lam)
+        assert abs(h.cost() - nb["F"]) <= 1e-12 * nb["F"]
+        r = h.reduced_system(want_points=True, want_dense=False)
+        assert rel(r["U"][free], nb["U"][free]) < 1e-10 and rel(r["gc"][free], nb["gc"][free]) < 1e-10
+        assert rel(r["V"], nb["V"]) < 1e-10 and rel(r["gp"], nb["gp"]) < 1e-10
+        assert rel(r["gred"], gred) < 1e-8
+        assert rel(h.schur_matvec(v), Sv) < 1e-8
+        del nb, r
+        s = h.run(3)
+        cp, pts = h.state()
+    assert s["pcg_iterations"] == 0                       # the 10 000-camera cyclic reduction, not PCG
+    assert s["accepted"] >= 1 and s["final_cost"] < s["initial_cost"]
+    f1 = O.residuals(cp, p["cam_intr"], pts, p["obs_cam"], p["obs_pt"], p["obs_xy"])
+    assert abs(O.cost(f1, 1.0, "huber") - s["final_cost"]) <= 1e-10 * s["final_cost"]
+
+
+def test_cyclic_reduction_lm_trajectory_against_the_oracle(gpu):
+    """The oracle-side anchor of the cyclic reduction: 203 cameras on a street (1 206 unknowns, blocks of 96 scalars,
+    8 levels), the whole LM trajectory against the oracle's dense NumPy LM (numpy.linalg.solve on the dense reduced
+    system) -- same status, same number of steps, same costs along the way, same minimum, same cameras."""
+    p = synthetic.make_street(203, 5000, 22000, seed=51, outlier_frac=0.01)
+    res = O.lm_solve(p["cam_pose"], p["cam_intr"], p["cam_fixed"], p["points"], p["obs_cam"], p["obs_pt"], p["obs_xy"],
+                     f_scale=1.0, max_iter=25)
+    arr = _capi.Arrays.from_dict(p)
+    with _capi.Handle(arr, loss="huber", f_scale=1.0, max_iter=25, linear_solver="cyclic_reduction") as h:
+        costs = []
+        for _ in range(25):                       # one LM step at a time: the cost after every step
+            s = h.run(1)
+            costs.append(s["final_cost"])
+            if s["status"] != 0:
+                break
+        cp, pts = h.state()
+    assert s["pcg_iterations"] == 0
+    assert s["status"] == res["status"] and s["iterations"] == res["iterations"]
+    ref_costs = [hh[2] if hh[3] > 0 else hh[1] for hh in res["history"]]      # cost after each step (rejected: unchanged)
+    assert len(costs) == len(ref_costs)
+    np.testing.assert_allclose(costs, ref_costs, rtol=1e-7)
+    assert abs(s["final_cost"] - res["cost"]) <= 1e-8 * res["cost"]
+    np.testing.assert_allclose(cp, res["cam_pose"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(pts, res["points"], rtol=0, atol=1e-5)
