@@ -24,6 +24,7 @@
 #include "ba_dense_big.h"
 #include "ba_kernels.h"
 #include "ba_heavy.h"
+#include "ba_det.h"
 
 // ---- scratch of the no-allocation entry point (ba_eval_cost_noalloc, end of this file) ------------------------------
 // A file-scope device array instead of hipMalloc'd buffers: every GPU the library runs on holds its own copy (about
@@ -329,6 +330,13 @@ struct BaHandle {
     DevBuf<unsigned long long> stamps;  // diagnostic (ba_debug_stamps)
     DevBuf<double> px, pr, pz, pp, pq, pqv;  // PCG: x, r, z, p (double-buffered: pp / pq), q = S p
     DevBuf<PcgScalars> pcg_sc;
+    DevBuf<double> pcg_part;         // per-workgroup partial sums of the PCG's dot products (PcgPartials)
+    // deterministic build (ba_det.h): contribution tables and slabs
+    DetTables det;
+    DevBuf<long long> det_ck_lg;
+    DevBuf<int> det_c_ptr, det_c_idx, det_s_ptr;
+    DevBuf<unsigned> det_s_idx;
+    DevBuf<double> det_cam_slab, det_blk_slab;
     DevBuf<double> dense_a;          // dense reduced system (one-workgroup solver, or the blocked multi-workgroup one)
     DevBuf<double> dense_linv;       // blocked solver: inverse factors of the diagonal blocks
     DevBuf<double> band_l, band_y, band_g, band_mid;  // block-banded factor, work vectors, separator system
@@ -399,9 +407,33 @@ int upload_pattern(BaHandle *h) {
     h->gc = h->U + nU;
     h->gred = h->gc + ng;
     h->sums = h->gred + ng;
+    if (h->opt.deterministic) {
+        build_det_tables(s, h->det);
+        const DetTables &t = h->det;
+        {
+            std::vector<long long> lg(t.ck_lg.begin(), t.ck_lg.end());
+            HIPCHK(h->det_ck_lg.upload(lg, st));
+        }
+        HIPCHK(h->det_c_ptr.upload(t.c_ptr, st));
+        HIPCHK(h->det_c_idx.upload(t.c_idx, st));
+        HIPCHK(h->det_s_ptr.upload(t.s_ptr, st));
+        HIPCHK(h->det_s_idx.upload(t.s_idx, st));
+        HIPCHK(h->det_cam_slab.alloc_grow((size_t)t.cam_rows * 33));
+        HIPCHK(h->det_blk_slab.alloc_grow((size_t)t.blk_rows * 36));
+    }
     HIPCHK(hipStreamSynchronize(st));
     h->pattern_uploaded = true;
     return BA_OK;
+}
+
+DetArgs det_args(BaHandle *h) {
+    DetArgs D{};
+    if (!h->opt.deterministic) return D;
+    D.cam_slab = h->det_cam_slab.p;
+    D.blk_slab = h->det_blk_slab.p;
+    D.ck_lg = h->det_ck_lg.p;
+    D.n_cl = h->det.n_cl; D.n_raw = h->det.n_raw; D.n_lg = h->det.n_lg;
+    return D;
 }
 
 int call_coll(BaHandle *h, void *ptr, int64_t n, int op) {
@@ -464,9 +496,15 @@ int do_build(BaHandle *h, bool timed) {
     hipStream_t st = h->stream;
     const int nf = h->sym.n_free;
     const size_t nred = (size_t)h->n_upper * 36 + (size_t)nf * 33 + 4;
-    HIPCHK(hipMemsetAsync(h->red.p, 0, (nred + BA_MAX_WORLD) * sizeof(double), st));
+    const bool det = h->opt.deterministic != 0;
+    // (deterministic build: k_det_reduce writes every element of S, U, g_c, g_red -- only the sums and the tail are cleared)
+    if (det) HIPCHK(hipMemsetAsync(h->red.p + nred - 4, 0, (4 + BA_MAX_WORLD) * sizeof(double), st));
+    else HIPCHK(hipMemsetAsync(h->red.p, 0, (nred + BA_MAX_WORLD) * sizeof(double), st));
     if (timed) HIPCHK(hipEventRecord(h->ev0, st));
-    if (h->n_chunks > 0) {
+    if (h->n_chunks > 0 && det) {
+        if (h->opt.loss == BA_LOSS_HUBER) hipLaunchKernelGGL((k_build_det<BA_LOSS_HUBER>), dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, build_args(h), det_args(h));
+        else hipLaunchKernelGGL((k_build_det<-1>), dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, build_args(h), det_args(h));
+    } else if (h->n_chunks > 0) {
         BuildArgs A = build_args(h);
         if (h->stamps.n) {
             A.stamps = h->stamps.p;
@@ -479,7 +517,13 @@ int do_build(BaHandle *h, bool timed) {
         }
     }
     if (timed) HIPCHK(hipEventRecord(h->ev1, st));
-    if (h->n_heavy > 0) hipLaunchKernelGGL(k_build_heavy, dim3(h->n_heavy), dim3(256), 0, st, build_args(h), heavy_args(h));
+    if (h->n_heavy > 0) hipLaunchKernelGGL(k_build_heavy, dim3(h->n_heavy), dim3(256), 0, st, build_args(h), heavy_args(h), det_args(h));
+    if (det) {
+        const long long n_el = (long long)h->n_upper * 36 + (long long)nf * 33;
+        if (n_el > 0)
+            hipLaunchKernelGGL(k_det_reduce, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, st, nf, h->n_upper, h->det_c_ptr.p, h->det_c_idx.p,
+                               h->det_s_ptr.p, h->det_s_idx.p, h->det_cam_slab.p, h->det_blk_slab.p, h->S, h->U, h->gc, h->gred);
+    }
     if (!h->coll) {
         // single GPU: nothing has to happen between the kernels behind the build -- two launches instead of four
         if (nf > 0)
@@ -532,8 +576,16 @@ int do_pcg(BaHandle *h, int *iters_out) {
         h->minv_valid = true;
     }
     HIPCHK(hipMemsetAsync(h->pcg_sc.p, 0, sizeof(PcgScalars), st));
-    hipLaunchKernelGGL(k_pcg_init, dim3(nb_cam), dim3(256), 0, st, nf, h->gred, h->Minv.p, h->px.p, h->pr.p, h->pz.p,
-                       h->pcg_sc.p);
+    PcgPartials pp{};
+    {
+        HIPCHK(h->pcg_part.alloc_grow((size_t)7 * nb_cam + (size_t)2 * nb_row));
+        double *q = h->pcg_part.p;
+        for (int k = 0; k < 3; ++k) { pp.rz[k] = q; q += nb_cam; pp.rn[k] = q; q += nb_cam; }
+        pp.bb = q; q += nb_cam;
+        pp.pq[0] = q; pp.pq[1] = q + nb_row;
+        pp.nb_cam = nb_cam; pp.nb_row = nb_row;
+    }
+    hipLaunchKernelGGL(k_pcg_init, dim3(nb_cam), dim3(256), 0, st, nf, h->gred, h->Minv.p, h->px.p, h->pr.p, h->pz.p, pp);
     const double tol2 = h->opt.pcg_tol * h->opt.pcg_tol;
     const int max_it = h->opt.pcg_max_iter > 0 ? h->opt.pcg_max_iter : 500;
     const int batch = 16;
@@ -543,9 +595,9 @@ int do_pcg(BaHandle *h, int *iters_out) {
         for (; it < end; ++it) {
             double *p_in = (it & 1) ? h->pq.p : h->pp.p, *p_out = (it & 1) ? h->pp.p : h->pq.p;
             hipLaunchKernelGGL(k_pcg_a, dim3(nb_row), dim3(256), 0, st, nf, it, tol2, h->bsr_row.p, h->bsr_col.p,
-                               h->bsr_src.p, h->S, h->pz.p, p_in, p_out, h->pqv.p, h->pcg_sc.p);
+                               h->bsr_src.p, h->S, h->pz.p, p_in, p_out, h->pqv.p, h->pcg_sc.p, pp);
             hipLaunchKernelGGL(k_pcg_b, dim3(nb_cam), dim3(256), 0, st, nf, it, h->Minv.p, p_out, h->pqv.p, h->px.p,
-                               h->pr.p, h->pz.p, h->pcg_sc.p);
+                               h->pr.p, h->pz.p, h->pcg_sc.p, pp);
         }
         if (!h->hpcg_pinned) HIPCHK(hipHostMalloc((void **)&h->hpcg_pinned, sizeof(PcgScalars), hipHostMallocDefault));
         HIPCHK(hipMemcpyAsync(h->hpcg_pinned, h->pcg_sc.p, sizeof(PcgScalars), hipMemcpyDeviceToHost, st));
@@ -695,7 +747,10 @@ int step_tail(BaHandle *h, const int *solve_info) {
         B.state = h->state.p;
         B.inv_fs2 = 1.0 / (h->opt.f_scale * h->opt.f_scale);
         B.half_fs2 = 0.5 * h->opt.f_scale * h->opt.f_scale;
-        if (h->n_chunks > 0) {
+        if (h->n_chunks > 0 && h->opt.deterministic) {
+            if (h->opt.loss == BA_LOSS_HUBER) hipLaunchKernelGGL((k_backsub_det<BA_LOSS_HUBER>), dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, B);
+            else hipLaunchKernelGGL((k_backsub_det<-1>), dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, B);
+        } else if (h->n_chunks > 0) {
             if (h->opt.loss == BA_LOSS_HUBER) hipLaunchKernelGGL((k_backsub<BA_LOSS_HUBER>), dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, B);
             else hipLaunchKernelGGL((k_backsub<-1>), dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, B);
         }
@@ -727,7 +782,8 @@ int do_step(BaHandle *h) {
     const int n_red = s.n_free * 6;
     bool direct = false;
     const int ls = h->opt.linear_solver;
-    const bool can_dense = n_red <= BA_DENSE_MAX, can_band = s.band <= BA_BAND_MAX, can_big = n_red <= BA_DENSE_BIG_MAX;
+    // (the two-sided banded solver merges its two halves with fp64 atomics: not in deterministic mode)
+    const bool can_dense = n_red <= BA_DENSE_MAX, can_band = s.band <= BA_BAND_MAX && !h->opt.deterministic, can_big = n_red <= BA_DENSE_BIG_MAX;
     // "a genuine dense contraction": at least a quarter of the 6x6 blocks of S are there (every camera shares landmarks
     // with most others); a sparse S of that size is cheaper through PCG
     const bool dense_pattern = (double)h->n_full >= 0.25 * (double)s.n_free * (double)s.n_free;
@@ -826,6 +882,7 @@ int check_options(BaOptions &o) {
     if (!(o.lambda0 > 0.0)) o.lambda0 = 1e-4;
     if (!(o.pcg_tol > 0.0)) o.pcg_tol = 1e-8;
     if (!(o.curv_floor > 0.0) || o.curv_floor > 1.0) o.curv_floor = 0.1;
+    o.deterministic = o.deterministic ? 1 : 0;
     return BA_OK;
 }
 
@@ -866,7 +923,8 @@ int alloc_work(BaHandle *h) {
 int build_structure(BaHandle *h, const HostProblem &hp, int n_cams, int n_points, int64_t n_obs) {
     int e;
     const char *msg = "";
-    if ((e = analyze_structure(n_cams, n_points, n_obs, hp.cam_fixed.data(), hp.obs_cam.data(), hp.obs_pt.data(), h->sym, &msg)))
+    if ((e = analyze_structure(n_cams, n_points, n_obs, hp.cam_fixed.data(), hp.obs_cam.data(), hp.obs_pt.data(), h->sym, &msg,
+                               h->opt.deterministic != 0)))
         return fail(e, "%s", msg);
     const bool tm_on = getenv("BA_TIME") != nullptr;
     double tl = now_ms();
@@ -965,7 +1023,7 @@ int append_tail(BaHandle *h, const HostProblem &hp, int nc2, int np2, int64_t no
     Symbolic t;
     const char *msg = "";
     int e;
-    if ((e = analyze_structure(nc2, (int)tail_pts.size(), no2 - no1, hp.cam_fixed.data(), t_cam.data(), t_pt.data(), t, &msg)))
+    if ((e = analyze_structure(nc2, (int)tail_pts.size(), no2 - no1, hp.cam_fixed.data(), t_cam.data(), t_pt.data(), t, &msg, s.deterministic)))
         return fail(e, "%s", msg);
     if (t.n_heavy > 0) return BA_OK;
     // ---- merge the tail into the handle's structure ----
@@ -1158,6 +1216,8 @@ int ba_set_values(BaHandle *h, const BaProblem *prob, const BaOptions *opt) {
         o = *opt;
         o.device = h->opt.device;
         if ((e = check_options(o))) return e;
+        if (o.deterministic != h->opt.deterministic)
+            return fail(BA_ERR_INVALID, "ba_set_values: BaOptions.deterministic belongs to the analysed structure and cannot change on a handle");
     }
     (void)hipSetDevice(h->device);
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -1198,6 +1258,8 @@ int ba_append(BaHandle *h, const BaProblem *grown, const BaOptions *opt, int32_t
         o = *opt;
         o.device = h->opt.device;
         if ((e = check_options(o))) return e;
+        if (o.deterministic != h->opt.deterministic)
+            return fail(BA_ERR_INVALID, "ba_append: BaOptions.deterministic belongs to the analysed structure and cannot change on a handle");
     }
     (void)hipSetDevice(h->device);
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -1596,6 +1658,7 @@ int ba_debug_stamps(BaHandle *h, unsigned long long *out, long long capacity) {
     if (int eu = usable(h)) return eu;
     (void)hipSetDevice(h->device);
     if (capacity < (long long)h->n_chunks * 12) return fail(BA_ERR_INVALID, "stamp buffer too small");
+    if (h->opt.deterministic) return fail(BA_ERR_UNSUPPORTED, "no stamped variant of the deterministic build");
     HIPCHK(h->stamps.alloc((size_t)h->n_chunks * 12));
     HIPCHK(hipMemset(h->stamps.p, 0, (size_t)h->n_chunks * 12 * 8));
     int e = do_build(h, false);

@@ -17,7 +17,10 @@ struct HeavyArgs {
     double *hv_t;                 // scratch: T = W L^-T per heavy observation [(obs - hv_obs[0]) * 18]
 };
 
-__global__ __launch_bounds__(256) void k_build_heavy(const BuildArgs A, const HeavyArgs H) {
+// D.cam_slab != nullptr: the deterministic build (ba_det.h) -- every sum that the atomic mode adds into U, g_c, g_red
+// and S goes, with plain stores, to a slab row of its own instead (one per observation, one per observation pair);
+// k_det_reduce adds the rows up in a fixed order.
+__global__ __launch_bounds__(256) void k_build_heavy(const BuildArgs A, const HeavyArgs H, const DetArgs D) {
     __shared__ double sRed[4];
     const int hp = blockIdx.x, tid = threadIdx.x;
     const long long ob = H.hv_obs[hp];
@@ -53,7 +56,16 @@ __global__ __launch_bounds__(256) void k_build_heavy(const BuildArgs A, const He
         vs[7] += Ln.Jp[0][1] * wr0 + Ln.Jp[1][1] * wr1;
         vs[8] += Ln.Jp[0][2] * wr0 + Ln.Jp[1][2] * wr1;
         const int f = A.cam_free[cam];
-        if (f >= 0) {
+        if (f >= 0 && D.cam_slab) {
+            double *row = &D.cam_slab[(size_t)(D.n_cl + (ob - H.hv_obs[0]) + o) * 33];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+#pragma unroll
+                for (int j = i; j < 6; ++j)
+                    row[ut6(i, j)] = Ln.wh[0] * Ln.Jc[0][i] * Ln.Jc[0][j] + Ln.wh[1] * Ln.Jc[1][i] * Ln.Jc[1][j];
+                row[21 + i] = Ln.Jc[0][i] * wr0 + Ln.Jc[1][i] * wr1;
+            }
+        } else if (f >= 0) {
             double *up = &A.U[(size_t)f * 21], *gp = &A.gc[(size_t)f * 6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
@@ -119,7 +131,8 @@ __global__ __launch_bounds__(256) void k_build_heavy(const BuildArgs A, const He
             const double w2 = wj0 * Ln.Jp[0][2] + wj1 * Ln.Jp[1][2];
             const double t0 = w0 * i00, t1 = w0 * i10 + w1 * i11, t2 = w0 * i20 + w1 * i21 + w2 * i22;
             tp[i * 3] = t0; tp[i * 3 + 1] = t1; tp[i * 3 + 2] = t2;
-            atomicAdd(&A.gred[(size_t)f * 6 + i], -(t0 * u0 + t1 * u1 + t2 * u2));
+            if (D.cam_slab) D.cam_slab[(size_t)(D.n_cl + (ob - H.hv_obs[0]) + o) * 33 + 27 + i] = -(t0 * u0 + t1 * u1 + t2 * u2);
+            else atomicAdd(&A.gred[(size_t)f * 6 + i], -(t0 * u0 + t1 * u1 + t2 * u2));
         }
     }
     __threadfence();
@@ -138,6 +151,18 @@ __global__ __launch_bounds__(256) void k_build_heavy(const BuildArgs A, const He
             double tcr[18];
 #pragma unroll
             for (int k = 0; k < 18; ++k) tcr[k] = tc[k];
+            if (D.blk_slab) {
+                // the pair's block as it is (-T_a T_c^T); the contribution table carries the transposition / the second,
+                // transposed use of a camera that observes the point twice
+                double *row_out = &D.blk_slab[(size_t)(D.n_raw + D.n_lg + H.hv_pair[hp] + row + (c - a)) * 36];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    const double a0 = ta[r * 3], a1 = ta[r * 3 + 1], a2 = ta[r * 3 + 2];
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) row_out[r * 6 + q] = -(a0 * tcr[q * 3] + a1 * tcr[q * 3 + 1] + a2 * tcr[q * 3 + 2]);
+                }
+                continue;
+            }
 #pragma unroll
             for (int r = 0; r < 6; ++r) {
                 const double a0 = ta[r * 3], a1 = ta[r * 3 + 1], a2 = ta[r * 3 + 2];

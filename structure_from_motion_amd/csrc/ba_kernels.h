@@ -59,6 +59,14 @@ struct BuildArgs {
     unsigned long long *stamps;     // diagnostic build only
 };
 
+// slabs of the deterministic build (ba_det.h; layout: DetTables in ba_symbolic.h); cam_slab == nullptr: atomic mode
+struct DetArgs {
+    double *cam_slab;             // rows of 33 doubles
+    double *blk_slab;             // rows of 36 doubles
+    const long long *ck_lg;       // [n_chunks + 1] later-round rows of each chunk, relative to n_raw
+    long long n_cl, n_raw, n_lg;
+};
+
 __global__ void k_cam_prep(int n_cams, const double *__restrict__ pose, const double *__restrict__ intr,
                            double *__restrict__ aux) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -827,14 +835,33 @@ __global__ void k_block_jacobi(int nf, const double *__restrict__ S, const int *
 //   k_pcg_a(it): p = z + beta p_old (recomputed on the fly for the gathered columns, p is
 //                double-buffered), q = S p with one wave per block row, pq = p.q
 //   k_pcg_b(it): x += alpha p, r -= alpha q, z = M^-1 r, rz = r.z, rn = r.r   (one lane per camera)
-// rz / rn rotate through three slots and pq through two so that a launch never zeroes a slot that
-// another workgroup of the same launch still reads.
+// The dot products are NOT accumulated by atomics (whose order would vary from run to run): every workgroup stores
+// its partial sum in a slot of its own, and every workgroup of the NEXT launch adds the partials up itself, in the same
+// fixed order -- all workgroups see the same bits, and so does every run.  rz / rn rotate through three sets of
+// partials and pq through two so that a launch never overwrites a set that another workgroup of the same launch reads.
 struct PcgScalars {
-    double rz[3], pq[2], rn[3], bnorm2, done, iters, pad;
+    double done, iters, pad0, pad1;
 };
+struct PcgPartials {
+    double *rz[3], *rn[3], *bb;   // [nb_cam] each: one slot per workgroup of k_pcg_init / k_pcg_b
+    double *pq[2];                // [nb_row] each: one slot per workgroup of k_pcg_a
+    int nb_cam, nb_row;
+};
+// sum of n partials, the same bits in every thread of every workgroup: thread t adds elements t, t + 256, ... in
+// order, then the fixed tree of block_sum256
+__device__ __forceinline__ double pcg_total(const double *__restrict__ part, int n, double *red) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+    s = wave_sum_dpp(s);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = s;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
 
-__global__ void k_pcg_init(int nf, const double *__restrict__ gred, const double *__restrict__ Minv, double *__restrict__ x,
-                           double *__restrict__ r, double *__restrict__ z, PcgScalars *sc) {
+__global__ __launch_bounds__(256) void k_pcg_init(int nf, const double *__restrict__ gred, const double *__restrict__ Minv, double *__restrict__ x,
+                           double *__restrict__ r, double *__restrict__ z, PcgPartials pp) {
     __shared__ double red[4];
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     double rz = 0.0, bb = 0.0;
@@ -856,22 +883,28 @@ __global__ void k_pcg_init(int nf, const double *__restrict__ gred, const double
     }
     rz = block_sum256(rz, red);
     bb = block_sum256(bb, red);
-    if (threadIdx.x == 0) { atomicAdd(&sc->rz[0], rz); atomicAdd(&sc->bnorm2, bb); }
+    if (threadIdx.x == 0) { pp.rz[0][blockIdx.x] = rz; pp.bb[blockIdx.x] = bb; pp.rn[0][blockIdx.x] = bb; }
 }
 
 __global__ __launch_bounds__(256) void k_pcg_a(int nf, int it, double tol2, const int *__restrict__ bsr_row,
                                                const int *__restrict__ bsr_col, const int *__restrict__ bsr_src,
                                                const double *__restrict__ S, const double *__restrict__ z,
                                                const double *__restrict__ p_in, double *__restrict__ p_out,
-                                               double *__restrict__ q, PcgScalars *sc) {
+                                               double *__restrict__ q, PcgScalars *sc, PcgPartials pp) {
     __shared__ double red[4];
     if (sc->done != 0.0) return;
-    const double rz_cur = sc->rz[it % 3];
-    if (!(sc->rn[it % 3] > tol2 * sc->bnorm2) && it > 0) {  // converged after iteration it-1 (same test in every workgroup)
+    const double rz_cur = pcg_total(pp.rz[it % 3], pp.nb_cam, red);
+    const double rn_cur = pcg_total(pp.rn[it % 3], pp.nb_cam, red);
+    const double bnorm2 = pcg_total(pp.bb, pp.nb_cam, red);
+    if (!(rn_cur > tol2 * bnorm2) && it > 0) {  // converged after iteration it-1 (same test, same bits, in every workgroup)
         if (blockIdx.x == 0 && threadIdx.x == 0) { sc->done = 1.0; sc->iters = it; }
         return;
     }
-    const double beta = (it > 0 && sc->rz[(it + 2) % 3] > 0.0) ? rz_cur / sc->rz[(it + 2) % 3] : 0.0;
+    double beta = 0.0;
+    if (it > 0) {
+        const double rz_prev = pcg_total(pp.rz[(it + 2) % 3], pp.nb_cam, red);
+        if (rz_prev > 0.0) beta = rz_cur / rz_prev;
+    }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int f = blockIdx.x * 4 + wv;
     const int a = lane & 7, slot = lane >> 3;
@@ -906,17 +939,18 @@ __global__ __launch_bounds__(256) void k_pcg_a(int nf, int it, double tol2, cons
         }
     }
     pq = block_sum256(pq, red);
-    if (threadIdx.x == 0) atomicAdd(&sc->pq[it & 1], pq);
+    if (threadIdx.x == 0) pp.pq[it & 1][blockIdx.x] = pq;
 }
 
 __global__ __launch_bounds__(256) void k_pcg_b(int nf, int it, const double *__restrict__ Minv, const double *__restrict__ p,
                                                const double *__restrict__ q, double *__restrict__ x,
-                                               double *__restrict__ r, double *__restrict__ z, PcgScalars *sc) {
+                                               double *__restrict__ r, double *__restrict__ z, PcgScalars *sc, PcgPartials pp) {
     __shared__ double red[4];
     if (sc->done != 0.0) return;
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    const double pqv = sc->pq[it & 1];
-    const double alpha = (pqv > 0.0) ? sc->rz[it % 3] / pqv : 0.0;
+    const double pqv = pcg_total(pp.pq[it & 1], pp.nb_row, red);
+    const double rz_cur = pcg_total(pp.rz[it % 3], pp.nb_cam, red);
+    const double alpha = (pqv > 0.0) ? rz_cur / pqv : 0.0;
     double rz = 0.0, rn = 0.0;
     if (f < nf) {
         double rv[6];
@@ -939,12 +973,8 @@ __global__ __launch_bounds__(256) void k_pcg_b(int nf, int it, const double *__r
     }
     rz = block_sum256(rz, red);
     rn = block_sum256(rn, red);
-    if (threadIdx.x == 0) { atomicAdd(&sc->rz[(it + 1) % 3], rz); atomicAdd(&sc->rn[(it + 1) % 3], rn); }
+    if (threadIdx.x == 0) { pp.rz[(it + 1) % 3][blockIdx.x] = rz; pp.rn[(it + 1) % 3][blockIdx.x] = rn; }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        // slots nobody touches in this launch or the next k_pcg_a
-        sc->pq[(it + 1) & 1] = 0.0;
-        sc->rz[(it + 2) % 3] = 0.0;
-        sc->rn[(it + 2) % 3] = 0.0;
         sc->iters = it + 1;
         if (!(pqv > 0.0)) sc->done = 1.0;  // S p . p <= 0: stop (x keeps the last good iterate)
     }

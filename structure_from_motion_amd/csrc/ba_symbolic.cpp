@@ -31,11 +31,15 @@ void parallel_for(int64_t n, F fn) {
 }  // namespace
 
 int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *cam_fixed,
-                      const int32_t *obs_cam, const int32_t *obs_pt, Symbolic &s, const char **err) {
+                      const int32_t *obs_cam, const int32_t *obs_pt, Symbolic &s, const char **err, bool deterministic) {
     const bool tm_on = getenv("BA_TIME") != nullptr;
     auto tm_t0 = std::chrono::steady_clock::now();
     auto tick = [&](const char *what) { if (tm_on) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[symbolic] %-22s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(t - tm_t0).count()); tm_t0 = t; } };
     s = Symbolic();
+    s.deterministic = deterministic;
+    // longest track on the chunk path (longer: heavy point).  The atomic-free build has no path for a camera without a
+    // local slot, so there a point must fit the slots of one chunk.
+    const int max_chunk_track = deterministic ? CHUNK_CAMS_WIDE : CHUNK_OBS;
     s.n_cams = n_cams;
     s.n_points = n_points;
     s.n_obs = n_obs;
@@ -88,10 +92,10 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
         std::vector<int32_t> tmp(n_points), head(n_cams + 2);
         int n_obs_pts = 0, n_heavy = 0;  // (n_obs_pts: the points that go into chunks)
         for (int i = 0; i < n_points; ++i)
-            if (cnt[i] > 0 && cnt[i] <= CHUNK_OBS) tmp[n_obs_pts++] = i;
+            if (cnt[i] > 0 && cnt[i] <= max_chunk_track) tmp[n_obs_pts++] = i;
         int n_un = n_obs_pts;
         for (int i = 0; i < n_points; ++i)
-            if (cnt[i] > CHUNK_OBS) s.pt_order[n_un++] = i, ++n_heavy;  // heavy points: own kernels, after the chunked ones
+            if (cnt[i] > max_chunk_track) s.pt_order[n_un++] = i, ++n_heavy;  // heavy points: own kernels, after the chunked ones
         for (int i = 0; i < n_points; ++i)
             if (cnt[i] == 0) s.pt_order[n_un++] = i;  // unobserved points last, in index order
         s.n_pts_chunked = n_obs_pts;
@@ -261,6 +265,17 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
             fidx.resize(L);
             for (int a = 0; a < L; ++a) fidx[a] = s.cam_free[s.o_cam[b + a]];
             bool cut = cur_obs + L > CHUNK_OBS || cur_pts + 1 > CHUNK_PTS;
+            if (!cut && deterministic && cur_cams + L > CHUNK_CAMS_WIDE) {
+                // (atomic-free build: every camera of a chunk needs a local slot)
+                int newc = 0;
+                for (int a = 0; a < L; ++a) {
+                    if (fidx[a] < 0) continue;
+                    bool seen = cam_stamp[fidx[a]] == chunk;
+                    for (int a2 = 0; a2 < a && !seen; ++a2) seen = fidx[a2] == fidx[a];
+                    if (!seen) ++newc;
+                }
+                if (cur_cams + newc > CHUNK_CAMS_WIDE) cut = true;
+            }
             if (!cut && cur_obs >= CHUNK_OBS / 4) {
                 // soft cut: would this point overflow the LDS tiles?
                 int newc = 0, newp = 0;
@@ -484,6 +499,78 @@ void finalize_pattern(Symbolic &s, const std::vector<int64_t> &extra_keys) {
         s.bsr_col[pos] = j;
         s.bsr_src[pos] = (int32_t)k;
     }
+}
+
+// Contribution tables of the atomic-free build (ba_symbolic.h); after finalize_pattern.
+void build_det_tables(const Symbolic &s, DetTables &t) {
+    t = DetTables();
+    const int n_chunks = (int)s.ck_obs.size() - 1;
+    const int half = CHUNK_OBS / 2;
+    t.n_cl = (int64_t)s.ck_cam_list.size();
+    t.n_raw = (int64_t)s.raw_keys.size();
+    t.ck_lg.assign(n_chunks + 1, 0);
+    for (int c = 0; c < n_chunks; ++c) {
+        const int np_ = s.ck_pair[c + 1] - s.ck_pair[c];
+        const int n_groups = s.ck_pgrp[s.ck_pair[c] + c + np_];
+        t.ck_lg[c + 1] = t.ck_lg[c] + std::max(0, n_groups - half);
+    }
+    t.n_lg = t.ck_lg[n_chunks];
+    const int64_t n_hobs = s.hv_obs.empty() ? 0 : s.hv_obs.back() - s.hv_obs.front();
+    t.cam_rows = t.n_cl + n_hobs;
+    t.blk_rows = t.n_raw + t.n_lg + (int64_t)s.hv_keys.size();
+    // ---- cameras
+    const int nf = s.n_free;
+    t.c_ptr.assign(nf + 1, 0);
+    for (int64_t r = 0; r < t.n_cl; ++r) t.c_ptr[s.ck_cam_list[r] + 1]++;
+    for (int64_t o = 0; o < n_hobs; ++o) {
+        const int f = s.cam_free[s.o_cam[s.hv_obs.front() + o]];
+        if (f >= 0) t.c_ptr[f + 1]++;
+    }
+    for (int f = 0; f < nf; ++f) t.c_ptr[f + 1] += t.c_ptr[f];
+    t.c_idx.resize(t.c_ptr[nf]);
+    {
+        std::vector<int32_t> fill(t.c_ptr.begin(), t.c_ptr.end() - 1);
+        for (int64_t r = 0; r < t.n_cl; ++r) t.c_idx[fill[s.ck_cam_list[r]]++] = (int32_t)r;
+        for (int64_t o = 0; o < n_hobs; ++o) {
+            const int f = s.cam_free[s.o_cam[s.hv_obs.front() + o]];
+            if (f >= 0) t.c_idx[fill[f]++] = (int32_t)(t.n_cl + o);
+        }
+    }
+    // ---- blocks: (destination slot, slab row | transposed flag) in ascending row order per slot
+    const size_t nu = s.upper_keys.size();
+    t.s_ptr.assign(nu + 1, 0);
+    auto each = [&](auto &&emit) {
+        for (int c = 0; c < n_chunks; ++c) {
+            const int qb = s.ck_pair[c], np_ = s.ck_pair[c + 1] - qb;
+            const int32_t *pg = &s.ck_pgrp[qb + c];
+            for (int l = 0; l < np_ && l < half; ++l)
+                if (pg[l] < std::min(pg[l + 1], half)) emit(s.ck_pair_slot[qb + l], (uint32_t)(qb + l));
+        }
+        for (int c = 0; c < n_chunks; ++c) {
+            const int qb = s.ck_pair[c], np_ = s.ck_pair[c + 1] - qb;
+            const int32_t *pg = &s.ck_pgrp[qb + c];
+            for (int l = 0; l < np_; ++l)
+                for (int g = std::max(pg[l], half); g < pg[l + 1]; ++g)
+                    emit(s.ck_pair_slot[qb + l], (uint32_t)(t.n_raw + t.ck_lg[c] + (g - half)));
+        }
+        for (size_t k = 0; k < s.hv_pair_slot.size(); ++k) {
+            const int32_t sw = s.hv_pair_slot[k];
+            if (sw < 0) continue;
+            const uint32_t row = (uint32_t)(t.n_raw + t.n_lg + (int64_t)k);
+            const bool tr = (sw & HV_SLOT_TRANSPOSED) != 0, twice = (sw & HV_SLOT_TWICE) != 0;
+            if (twice) {   // one camera observing the point twice: both orders land in its diagonal block
+                emit(sw & HV_SLOT_MASK, row);
+                emit(sw & HV_SLOT_MASK, row | 0x80000000u);
+            } else {
+                emit(sw & HV_SLOT_MASK, tr ? (row | 0x80000000u) : row);
+            }
+        }
+    };
+    each([&](int32_t slot, uint32_t) { t.s_ptr[slot + 1]++; });
+    for (size_t k = 0; k < nu; ++k) t.s_ptr[k + 1] += t.s_ptr[k];
+    t.s_idx.resize(t.s_ptr[nu]);
+    std::vector<int32_t> fill(t.s_ptr.begin(), t.s_ptr.end() - 1);
+    each([&](int32_t slot, uint32_t row) { t.s_idx[fill[slot]++] = row; });
 }
 
 }  // namespace ba

@@ -71,11 +71,35 @@ struct Symbolic {
     std::vector<int32_t> bsr_src;    // [nnz_full] upper slot; bit 31 set = use the transposed block
     int64_t n_direct_pairs = 0, n_direct_cam_obs = 0;
     int max_chunk_cams = 0, max_chunk_pairs = 0;
+    bool deterministic = false;      // analysed for the atomic-free build (see analyze_structure)
 };
 
+// Contribution tables of the deterministic (atomic-free) build: every partial result of the build kernels has a slab
+// row of its own, written with plain stores, and each accumulator of the reduced system is the sum of its rows in the
+// fixed order listed here (ascending row = chunk order, then later-round groups, then heavy points).
+//   camera slab, rows of 33 doubles (U 21, g_c 6, reduced-gradient part 6):
+//       row ck_cam[ck] + l            local camera l of chunk ck
+//       row n_cl + (o - hv_obs[0])    observation o of a heavy point
+//   block slab, rows of 36 doubles (one 6x6 partial Schur block, already signed):
+//       row ck_pair[ck] + l           local pair l (< CHUNK_OBS / 2) of chunk ck: the sum of its first-round groups
+//       row n_raw + ck_lg[ck] + g - CHUNK_OBS / 2     group g >= CHUNK_OBS / 2 of chunk ck (later rounds)
+//       row n_raw + n_lg + k          pair k of the heavy points' triangular lists
+struct DetTables {
+    std::vector<int64_t> ck_lg;      // [n_chunks + 1] first later-round row of each chunk (relative to n_raw)
+    int64_t n_cl = 0, n_raw = 0, n_lg = 0;
+    int64_t cam_rows = 0, blk_rows = 0;
+    std::vector<int32_t> c_ptr;      // [n_free + 1]
+    std::vector<int32_t> c_idx;      // camera-slab rows per free camera
+    std::vector<int32_t> s_ptr;      // [n_upper + 1]
+    std::vector<uint32_t> s_idx;     // block-slab rows per upper block; bit 31: add the row's block TRANSPOSED
+};
+void build_det_tables(const Symbolic &s, DetTables &t);
+
 // Phase A: ordering + chunking + this problem's own pair keys.  Returns 0 or a BA_ERR_* code.
+// deterministic: the structure for the atomic-free build -- no chunk holds more cameras than it has local slots
+// (CHUNK_CAMS_WIDE), and a point seen by more cameras than that is a heavy point.
 int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *cam_fixed,
-                      const int32_t *obs_cam, const int32_t *obs_pt, Symbolic &s, const char **err);
+                      const int32_t *obs_cam, const int32_t *obs_pt, Symbolic &s, const char **err, bool deterministic = false);
 // Phase B: final pattern = own keys U extra keys; resolves chunk-local pairs to block slots.
 void finalize_pattern(Symbolic &s, const std::vector<int64_t> &extra_keys);
 

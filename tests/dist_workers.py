@@ -92,7 +92,8 @@ def engine_sharded_solve(rank, world, port, out_dir):
     p, max_iter = _engine_problem()
     sh, pidx = badist.shard_points(p, rank, world)
     h = badist.create_sharded_handle(sh, rank, world, loss="huber", f_scale=1.0, max_iter=max_iter, device=0,
-                                     verbose=int(os.environ.get("BA_TEST_VERBOSE", "0")))
+                                     verbose=int(os.environ.get("BA_TEST_VERBOSE", "0")),
+                                     deterministic=int(os.environ.get("BA_TEST_DET", "0")))
     s = h.run()
     cp, pts = h.state()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), cp=cp, pts=pts, pidx=pidx, cost=s["final_cost"], status=s["status"],

@@ -204,6 +204,94 @@ def tight_for_existing(ref, name):
           f"reference stopped at {float(d['ref_cost']):.12e}) in {time.time() - t0:.0f}s")
 
 
+REF_CLOUDS = {"temple": "/root/reference/src/temple_new.ply",                             # 20 467 vertices (README.md:45)
+              "fountain": "/root/reference/results/Fountain_Results/fountain_best.ply"}   # 16 908 vertices (README.md:40)
+
+
+def read_ply_xyz(path):
+    """xyz of an ASCII PLY as the reference writes it (utils.py:334-353: `x y z r g b` per vertex).  Data, not source."""
+    with open(path) as fh:
+        n = None
+        for line in fh:
+            if line.startswith("element vertex"):
+                n = int(line.split()[-1])
+            if line.strip() == "end_header":
+                break
+        return np.loadtxt(fh, max_rows=n)[:, :3].astype(np.float64)
+
+
+def cloud_problem(which, visibility):
+    """A BASELINE.json config-1 / config-2 problem on the reference's OWN surviving structure: the points
+    are the vertices of the reference's output cloud, exactly as stored (its frame is the first camera's: the bulk sits at
+    depth 5-8 in front of the origin; a per cent of the vertices are the junk triangulations the reference keeps --
+    behind the cameras, a hundred units away -- and stay in).  The images are gone (.gitignore:1), so cameras and
+    observations are synthetic: cameras on a ring (Temple, 47) or an arc (Fountain, 11) through the origin around the
+    cloud's median, looking at it, intrinsics as Reconstruction.py:326-327; `visibility` "dense" = every point seen by a
+    window of the cameras nearest to its azimuth, "sfm" = what the reference's driver records.  A camera only
+    observes a point whose depth is at least a tenth of the ring radius in magnitude (the reference has no cheirality
+    test, utils.py:162: points behind a camera are observed "through its back", as in its own runs)."""
+    xyz = read_ply_xyz(REF_CLOUDS[which])
+    if which == "temple":
+        n_cams, K, fj, noise, mean_track, n_fixed, seed, n_seed = 47, (1520.4, 1525.9, 302.32, 246.87), 0.02, 0.35, 4.0, 1, 1236, 1500
+    else:
+        sc = 1600.0 / 3072.0
+        n_cams, K, fj, noise, mean_track, n_fixed, seed, n_seed = 11, (2759.48 * sc, 2764.16 * sc, 1520.69 * sc, 1006.81 * sc), 0.0, 0.4, 3.5, 2, 1235, 2500
+    if visibility == "sfm":
+        seed += 2
+    rng = np.random.default_rng(seed)
+    c = np.median(xyz, axis=0)
+    c[1] = 0.0
+    radius = float(np.hypot(c[0], c[2]))
+    th0 = np.arctan2(-c[0], c[2])                      # azimuth (about the centre) at which the ring passes the origin
+    ang = th0 + (np.linspace(0.0, 2 * np.pi, n_cams, endpoint=False) if n_cams > 12 else np.linspace(0.0, 1.8, n_cams))
+    C = c[None, :] + np.stack([radius * np.sin(ang), rng.normal(0, 0.05, n_cams), -radius * np.cos(ang)], axis=1)
+    from structure_from_motion_amd.geometry import matrix_to_rvec
+    cam_pose_gt = np.zeros((n_cams, 6))
+    Rm_all = np.zeros((n_cams, 3, 3))
+    for i in range(n_cams):
+        zax = (c - C[i]) / np.linalg.norm(c - C[i])
+        xax = np.cross([0.0, 1.0, 0.0], zax); xax /= np.linalg.norm(xax)
+        yax = np.cross(zax, xax)
+        Rm = np.stack([xax, yax, zax], axis=0)
+        Rm_all[i] = Rm
+        cam_pose_gt[i, :3] = matrix_to_rvec(Rm)
+        cam_pose_gt[i, 3:] = -Rm @ C[i]
+    f = 1.0 + rng.uniform(-fj, fj, n_cams)
+    cam_intr = np.stack([K[0] * f, K[1] * f, np.full(n_cams, K[2]), np.full(n_cams, K[3])], axis=1)
+    n_p = len(xyz)
+    depth = np.einsum("cj,pj->pc", Rm_all[:, 2, :], xyz) + cam_pose_gt[None, :, 5]          # (Np, Nc)
+    ok = np.abs(depth) >= 0.1 * radius
+    assert ok.any(axis=1).all()
+    if visibility == "dense":
+        L = synthetic._track_lengths(rng, n_p, int(round(mean_track * n_p)), max_track=min(n_cams, 24))
+        az = np.arctan2(xyz[:, 0] - c[0], -(xyz[:, 2] - c[2]))
+        dist = np.abs(((az[:, None] - ang[None, :] + np.pi) % (2 * np.pi)) - np.pi)           # angular distance to each camera
+        rank = np.argsort(dist + 100.0 * (~ok), axis=1, kind="stable")                        # usable cameras first, nearest first
+        L = np.minimum(L, ok.sum(axis=1))
+        L = np.maximum(L, np.minimum(2, ok.sum(axis=1)))
+        obs_pt = np.repeat(np.arange(n_p, dtype=np.int64), L)
+        within = np.arange(len(obs_pt), dtype=np.int64) - np.repeat(np.cumsum(L) - L, L)
+        obs_cam = rank[obs_pt, within].astype(np.int64)
+    else:
+        # the seed pair's points: the first n_seed vertices that both seed cameras can observe
+        both = np.flatnonzero(ok[:, 0] & ok[:, 1])[:n_seed]
+        rest = np.setdiff1d(np.arange(n_p), both)
+        cam_rest = 2 + (np.arange(len(rest)) * (n_cams - 2) // max(len(rest), 1))
+        for k in range(n_cams):                                                             # next usable camera
+            bad = ~ok[rest, cam_rest]
+            if not bad.any():
+                break
+            cam_rest[bad] = 2 + (cam_rest[bad] - 2 + 1) % (n_cams - 2)
+        obs_pt = np.concatenate([both, both, rest])
+        obs_cam = np.concatenate([np.zeros(len(both), np.int64), np.ones(len(both), np.int64), cam_rest.astype(np.int64)])
+    cam_fixed = np.zeros(n_cams, dtype=np.uint8)
+    cam_fixed[:n_fixed] = 1
+    prob = synthetic._finish(rng, cam_pose_gt, cam_intr, xyz, obs_cam, obs_pt, noise, 0.0, 1e-3, 1e-2, 1e-2, cam_fixed)
+    prob["name"] = f"{which} cloud of the reference ({n_p} vertices), {n_cams} cameras, {len(obs_pt)} observations, vis={visibility}"
+    print(prob["name"], f"radius {radius:.2f}; |depth| min {np.abs(depth[obs_pt, obs_cam]).min():.2f}")
+    return prob
+
+
 def config_size_case(ref, name, prob, f_scale, max_nfev):
     """A BASELINE.json configuration at FULL size (Temple 20 467 points, Fountain 16 908 points).  The reference would
     need about an hour of single-core Python per case for its max_nfev evaluations and stop far from the minimum
@@ -345,16 +433,19 @@ def main():
     if args.config_size:
         S = synthetic
         want = args.config_size.split(",")
+        # structure = the vertices of the reference's own output clouds (cloud_problem); --blob-structure: the generic
+        # ring problems of synthetic.make_config instead (what rounds 1 and 2 stored)
+        blob = os.environ.get("GOLDEN_BLOB_STRUCTURE") == "1"
         if "temple" in want:
-            config_size_case(ref, "temple_final", S.make_config("temple"), 1.0, 300)
+            config_size_case(ref, "temple_final", S.make_config("temple") if blob else cloud_problem("temple", "dense"), 1.0, 300)
         if "fountain" in want:
-            config_size_case(ref, "fountain_final", S.make_config("fountain"), 1.0, 300)
+            config_size_case(ref, "fountain_final", S.make_config("fountain") if blob else cloud_problem("fountain", "dense"), 1.0, 300)
         if "fountain_sfm" in want:
             # what the reference's driver really produces: seed-pair points with two observations, every
             # other point with exactly one; 11 images -> both seed cameras anchored
-            config_size_case(ref, "fountain_final_sfm", S.make_config("fountain_sfm"), 1.0, 300)
+            config_size_case(ref, "fountain_final_sfm", S.make_config("fountain_sfm") if blob else cloud_problem("fountain", "sfm"), 1.0, 300)
         if "temple_sfm" in want:
-            config_size_case(ref, "temple_final_sfm", S.make_config("temple_sfm"), 1.0, 300)
+            config_size_case(ref, "temple_final_sfm", S.make_config("temple_sfm") if blob else cloud_problem("temple", "sfm"), 1.0, 300)
         return
     if args.temple:
         # full size takes about an hour of single-core Python in the reference; --scale shrinks points /

@@ -102,3 +102,27 @@ def test_two_ranks_with_ten_thousand_replicated_cameras(gpu, tmp_path, monkeypat
     assert float(r0["cost"]) == float(r1["cost"])
     assert abs(float(r0["cost"]) - s["final_cost"]) <= 1e-9 * s["final_cost"]
     assert np.allclose(r0["cp"], cp, rtol=1e-6, atol=1e-7)
+
+
+def test_deterministic_mode_across_ranks(gpu, tmp_path, monkeypatch):
+    """BaOptions.deterministic on a sharded solve (determinism): two runs of the two-rank solve give the
+    same bits, and the two-rank cost equals the single handle's to 1e-13 (what differs is only where the partial sums of
+    the two shards are joined: inside one segmented sum, or by the all-reduce)."""
+    monkeypatch.setenv("BA_TEST_PROBLEM", "street203")
+    monkeypatch.setenv("BA_TEST_DET", "1")
+    p = synthetic.make_street(203, 5000, 22000, seed=51, outlier_frac=0.01)
+    arr = _capi.Arrays.from_dict(p)
+    s = _capi.solve(arr, loss="huber", f_scale=1.0, max_iter=25, deterministic=1)
+    runs = []
+    for rep in range(2):
+        d = tmp_path / f"rep{rep}"
+        d.mkdir()
+        mp.spawn(engine_sharded_solve, args=(2, _free_port(), str(d)), nprocs=2, join=True)
+        runs.append((np.load(d / "rank0.npz"), np.load(d / "rank1.npz")))
+    (a0, a1), (b0, b1) = runs
+    np.testing.assert_array_equal(a0["cp"], b0["cp"])
+    np.testing.assert_array_equal(a0["pts"], b0["pts"])
+    np.testing.assert_array_equal(a1["pts"], b1["pts"])
+    assert float(a0["cost"]) == float(b0["cost"]) == float(a1["cost"])
+    assert int(a0["iters"]) == s["iterations"] and int(a0["pcg"]) == 0
+    assert abs(float(a0["cost"]) - s["final_cost"]) <= 1e-13 * s["final_cost"]

@@ -810,7 +810,9 @@ def test_city_shard_10k_cameras(gpu):
     Sv, gred = O.reduced_matvec(nb, p["cam_fixed"], p["obs_cam"], p["obs_pt"], lam, v)
     with _capi.Handle(arr, loss="huber", f_scale=1.0) as h:
         h.build(lam)
-        assert abs(h.cost() - nb["F"]) <= 1e-12 * nb["F"]
+        # (25 M terms: the two summation orders -- NumPy's pairwise sum, the engine's per-chunk sums added in chunk order
+        # -- differ by 1.3e-11 relative; 1e-12 holds up to the 5 M observations of the Venice shape)
+        assert abs(h.cost() - nb["F"]) <= 1e-10 * nb["F"]
         r = h.reduced_system(want_points=True, want_dense=False)
         assert rel(r["U"][free], nb["U"][free]) < 1e-10 and rel(r["gc"][free], nb["gc"][free]) < 1e-10
         assert rel(r["V"], nb["V"]) < 1e-10 and rel(r["gp"], nb["gp"]) < 1e-10
