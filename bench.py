@@ -169,6 +169,25 @@ def other_configs(_capi, synthetic):
                      "pcg_iterations_per_lm_step": s["pcg_iterations"] / max(s["iterations"], 1),
                      "cost": [s["initial_cost"], s["final_cost"]]}
     out["ring1778_loop"] = ring
+    # The same ring with 1 % of its points seen a second time from far away (revisits): a ring PLUS a remainder of
+    # far-apart camera pairs.  AUTO = CG on the whole S preconditioned by the cyclic reduction of its in-band part;
+    # block-Jacobi PCG forced beside it
+    p = synthetic.make_config("ring1778_revisit")
+    rev = {"cameras": len(p["cam_pose"]), "observations": len(p["obs_cam"]),
+           "solver": "auto = CG preconditioned by the cyclic reduction of the in-band part; pcg_tol_1e-8 forces block-Jacobi PCG"}
+    for tag, kw in (("auto_bcr_preconditioned_cg", {}), ("pcg_tol_1e-8", dict(linear_solver="pcg", pcg_tol=1e-8))):
+        with _capi.Handle(_capi.Arrays.from_dict(p), loss="huber", f_scale=1.0, max_iter=300, **kw) as h:
+            h.run(1)
+            h.synchronize()
+            t0 = time.perf_counter()
+            s = h.run(10)
+            h.synchronize()
+            dt = time.perf_counter() - t0
+        steps = max(s["iterations"] - 1, 1)
+        rev[tag] = {"lm_steps": steps, "lm_iters_per_sec": steps / dt, "lm_pcg_iterations": s["pcg_iterations"],
+                    "pcg_iterations_per_lm_step": s["pcg_iterations"] / max(s["iterations"], 1),
+                    "cost": [s["initial_cost"], s["final_cost"]]}
+    out["ring1778_revisit"] = rev
     # Object-centric capture: 1024 cameras around one object, every pair of cameras shares landmarks -- S is full, the
     # "genuine dense contraction" of BASELINE.json's north_star: AUTO = blocked dense Cholesky on the fp64 matrix cores
     # (ba_dense_big.h); block-Jacobi PCG forced beside it.  The flop rate charges the whole LM step minus the build pass

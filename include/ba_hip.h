@@ -81,12 +81,18 @@ typedef struct BaOptions {
                               co-visible free cameras are at most 21 apart along a chain or a closed ring (in camera order,
                               or in an order the planner finds from the co-visibility graph when the numbering is not
                               along the trajectory);
-                              blocked dense Cholesky for a (nearly) full pattern up to 2048 free cameras; block-Jacobi
-                              PCG otherwise.  BANDED_CHOLESKY (chains, at most 16 apart): on request, and under AUTO only
+                              a chain / ring plus a remainder of far-apart pairs (revisits): CG preconditioned by the
+                              cyclic reduction of the in-band part;
+                              a (nearly) full pattern up to 2048 free cameras: blocked dense Cholesky or block-Jacobi PCG,
+                              whichever the first two steps time as faster; block-Jacobi PCG otherwise.  BANDED_CHOLESKY (chains, at most 16 apart): on request, and under AUTO only
                               for a chain that the cyclic reduction cannot plan (fewer than two blocks) */
     int32_t verbose;       /* 0 silent, 1 summary, 2 per-iteration table (<- verbose, :219) */
     int32_t device;        /* HIP device ordinal; -1 = current device */
-    int32_t deterministic; /* reserved (0) */
+    int32_t deterministic; /* 1: no floating-point sum whose order depends on timing (no fp64 atomics in LDS or HBM: owner-lane
+                              gathers, one slab row per partial result, fixed-order segmented sums; csrc/ba_det.h) -- the
+                              same inputs give the same bits, run after run, as the reference's single-threaded solve
+                              does (BundleAdjustment.py:210-220).  Slower build pass; belongs to the analysed structure
+                              (cannot change on a handle).  0 (default): the atomic kernels */
     int32_t reserved;
     double curv_floor;     /* Hessian weight of a residual component = max(rho' + 2 rho'' z, curv_floor * rho');
                               1.0 = plain IRLS, default 0.1 (in (0, 1]) */
@@ -175,10 +181,17 @@ int ba_analyze(const BaProblem *prob, BaAnalysis *out);
  * (free camera at (block, offset) or -1: the cameras are taken in index order, else in reverse Cuthill-McKee order) |
  * src[(m+n_init_slots)*(nb/6)^2]
  * | lvl_elim[levels+1] | lvl_op[levels+1] | elims[5 each: k, gu, gv, u, v] | ops[9 each: kind, dst, a0, b0, a1, b1, k0,
- * k1, init].  ok = 0 (only the header is written): the pattern is neither a chain nor a ring of bandwidth <= 21 cameras.
- * What the tests execute with NumPy to check the schedule against a dense solve.  (No reference counterpart: the
- * reference leaves the linear algebra to scipy.) */
+ * k1, init] | n_rest | pend_ptr[m+1] | pend[2 * pend_ptr[m]] (per block the right-hand-side updates it has received by the
+ * time it is eliminated, as (coupling slot, source block) pairs: the forward substitution of a NEW right-hand side through
+ * the stored factors).  ok = 0 (only the header is written): the pattern is neither a chain nor a ring of bandwidth <= 21
+ * cameras.  What the tests execute with NumPy to check the schedule against a dense solve.  (No reference counterpart:
+ * the reference leaves the linear algebra to scipy.) */
 int ba_bcr_plan(int32_t n_free, const int32_t *pairs, int64_t n_pairs, int32_t *out, int64_t capacity, int64_t *needed);
+/* The same, but a pattern that is a chain / ring PLUS a remainder (a revisit, a few long tracks: pairs of cameras further
+ * apart than any block holds) gets a schedule for its IN-BAND part when that part holds at least half of the off-diagonal
+ * blocks: header flag 4 is set and n_rest = the upper blocks left out (they appear in no src entry).  The engine uses
+ * that factorisation as the preconditioner of CG on the whole system (AUTO / CYCLIC_REDUCTION on such a pattern). */
+int ba_bcr_plan_rest(int32_t n_free, const int32_t *pairs, int64_t n_pairs, int32_t *out, int64_t capacity, int64_t *needed);
 
 /* ---- handle API: problem resident on the device across calls ------------------------ */
 BaHandle *ba_create(const BaProblem *prob, const BaOptions *opt);

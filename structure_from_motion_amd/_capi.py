@@ -26,7 +26,7 @@ EXPORTED = [
     "ba_get_state", "ba_get_cost", "ba_get_reduced_system", "ba_get_reduced_blocks", "ba_synchronize",
     "ba_set_values", "ba_set_collective_mode", "ba_get_stream", "ba_eval_cost_noalloc",
     "ba_eval_reprojection_errors_rt", "ba_get_reprojection_errors", "ba_rccl_unique_id", "ba_rccl_init", "ba_append",
-    "ba_bcr_plan",
+    "ba_bcr_plan", "ba_bcr_plan_rest",
 ]
 
 
@@ -102,6 +102,7 @@ def load():
     lib.ba_get_reprojection_errors.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ba_rccl_unique_id.argtypes = [C.c_void_p]
     lib.ba_bcr_plan.argtypes = [C.c_int32, P(C.c_int32), C.c_int64, P(C.c_int32), C.c_int64, P(C.c_int64)]
+    lib.ba_bcr_plan_rest.argtypes = [C.c_int32, P(C.c_int32), C.c_int64, P(C.c_int32), C.c_int64, P(C.c_int64)]
     lib.ba_rccl_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
     lib.ba_analyze.argtypes = [P(BaProblem), P(BaAnalysis)]
     lib.ba_create.argtypes = [P(BaProblem), P(BaOptions)]
@@ -135,18 +136,20 @@ def check(code):
         raise BaError(code, load().ba_last_error().decode("utf-8", "replace"))
 
 
-def bcr_plan(n_free, pairs):
+def bcr_plan(n_free, pairs, allow_rest=False):
     """The block-cyclic-reduction schedule for a pattern (host only, no GPU): ``pairs`` = (n, 2) free-camera index pairs
     of the upper blocks of S, diagonal included.  Returns None when the pattern has no schedule, else a dict of the
-    tables of ``csrc/ba_bcr.h`` (``src`` refers to the pairs in sorted unique order = the block order of S)."""
+    tables of ``csrc/ba_bcr.h`` (``src`` refers to the pairs in sorted unique order = the block order of S).
+    ``allow_rest``: accept a chain / ring plus a remainder (``ba_bcr_plan_rest``; ``n_rest`` = blocks left out)."""
     lib = load()
+    fn = lib.ba_bcr_plan_rest if allow_rest else lib.ba_bcr_plan
     pr = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
     need = C.c_int64(0)
     ptr = pr.ctypes.data_as(C.POINTER(C.c_int32))
-    check(lib.ba_bcr_plan(C.c_int32(n_free), ptr, C.c_int64(len(pr)), None, C.c_int64(0), C.byref(need)))
+    check(fn(C.c_int32(n_free), ptr, C.c_int64(len(pr)), None, C.c_int64(0), C.byref(need)))
     w = np.zeros(need.value, dtype=np.int32)
-    check(lib.ba_bcr_plan(C.c_int32(n_free), ptr, C.c_int64(len(pr)), w.ctypes.data_as(C.POINTER(C.c_int32)),
-                          C.c_int64(len(w)), C.byref(need)))
+    check(fn(C.c_int32(n_free), ptr, C.c_int64(len(pr)), w.ctypes.data_as(C.POINTER(C.c_int32)),
+             C.c_int64(len(w)), C.byref(need)))
     ok, cyclic, m, nt, nb, n_slots, n_init, levels = (int(v) for v in w[:8])
     if not ok:
         return None
@@ -166,6 +169,9 @@ def bcr_plan(n_free, pairs):
     plan["lvl_op"] = take(levels + 1)
     plan["elims"] = take(5 * int(plan["lvl_elim"][-1])).reshape(-1, 5)
     plan["ops"] = take(9 * int(plan["lvl_op"][-1])).reshape(-1, 9)
+    plan["n_rest"] = int(take(1)[0])
+    plan["pend_ptr"] = take(m + 1)
+    plan["pend"] = take(2 * int(plan["pend_ptr"][-1])).reshape(-1, 2)
     assert at[0] == len(w)
     return plan
 

@@ -45,6 +45,7 @@
 #include <vector>
 
 #include "ba_banded.h"  // band_readlane, band_rsqrt, band_wave_sync
+#include "ba_device.h"  // wave_sum_dpp
 #include "ba_dense.h"   // mfma_d4
 #include "ba_tile16.h" // bcr_potrf16
 
@@ -70,6 +71,13 @@ struct BcrPlan {
     std::vector<int32_t> lvl_elim, lvl_op;  // [levels + 1] offsets into elims / ops
     std::vector<BcrElim> elims;
     std::vector<BcrOp> ops;
+    // A plan "with a remainder": some blocks of S lie outside the chain / ring (a revisit, a few long tracks).  The
+    // schedule then factors the IN-BAND part of S only, and that factorisation is used as the preconditioner of a CG
+    // iteration on the whole S (do_bcr_pcg in ba_engine.hip); n_rest = upper blocks left out.
+    int64_t n_rest = 0;
+    // forward substitution of a NEW right-hand side through the stored factors (k_bcr_fwd): per block the updates it
+    // has received by the time it is eliminated, b_k -= W[slot] y_j, as (slot, j) pairs in schedule order
+    std::vector<int32_t> pend_ptr, pend;   // [m + 1], [2 * n]
     int levels() const { return (int)lvl_elim.size() - 1; }
 };
 
@@ -204,7 +212,9 @@ inline bool bcr_chain_order(int nf, const int64_t *keys, size_t nk, std::vector<
 
 // Plans the elimination for the pattern `keys` (sorted unique (i << 32 | j), i <= j, free-camera indices) with the
 // cameras taken in the order `order`.
-inline bool bcr_plan_with_order(int nf, const int64_t *keys, size_t nk, const std::vector<int32_t> &order, BcrPlan &P) {
+constexpr int BCR_MAX_BAND = 21;   // cameras per block of 128 scalars
+inline bool bcr_plan_with_order(int nf, const int64_t *keys, size_t nk, const std::vector<int32_t> &order, BcrPlan &P,
+                                bool allow_rest = false) {
     P = BcrPlan{};
     if (nf < 2) return false;
     std::vector<int32_t> pos(nf);
@@ -213,6 +223,8 @@ inline bool bcr_plan_with_order(int nf, const int64_t *keys, size_t nk, const st
     for (size_t q = 0; q < nk; ++q) {
         const int i = (int)(keys[q] >> 32), j = (int)(keys[q] & 0xffffffff), d = std::abs(pos[j] - pos[i]);
         if (d == 0) continue;
+        // (with a remainder allowed, pairs further apart than any block could hold do not set the bandwidth)
+        if (allow_rest && std::min(d, nf - d) > BCR_MAX_BAND) continue;
         if (2 * (int64_t)d <= nf) near_b = std::max(near_b, d);
         else wrap_b = std::max(wrap_b, nf - d);
     }
@@ -252,7 +264,10 @@ inline bool bcr_plan_with_order(int nf, const int64_t *keys, size_t nk, const st
     for (size_t q = 0; q < nk; ++q) {
         const int i = (int)(keys[q] >> 32), j = (int)(keys[q] & 0xffffffff);
         const int bi = P.cam_blk[i] >> 8, bj = P.cam_blk[j] >> 8, lo = std::min(bi, bj), hi = std::max(bi, bj);
-        if (!(hi == lo || hi == lo + 1 || (cyc && lo == 0 && hi == m - 1))) return false;
+        if (!(hi == lo || hi == lo + 1 || (cyc && lo == 0 && hi == m - 1))) {
+            if (!allow_rest) return false;
+            ++P.n_rest;
+        }
     }
     // pass 1: who is eliminated when, next to whom
     struct Lv { int k, u, v; };
@@ -351,6 +366,7 @@ inline bool bcr_plan_with_order(int nf, const int64_t *keys, size_t nk, const st
         // S block q = A[camera i rows][camera j columns], i <= j
         const int i = (int)(keys[q] >> 32), j = (int)(keys[q] & 0xffffffff);
         const int bi = P.cam_blk[i] >> 8, oi = P.cam_blk[i] & 255, bj = P.cam_blk[j] >> 8, oj = P.cam_blk[j] & 255;
+        if (!(bi == bj || std::abs(bi - bj) == 1 || (cyc && std::min(bi, bj) == 0 && std::max(bi, bj) == m - 1))) continue;   // remainder
         if (i == j) {
             P.src[((size_t)bi * cbt + oi) * cbt + oi] = (int32_t)q | BCR_SRC_SYMMETRISE;
         } else if (bi == bj) {   // lower triangle of the diagonal block: the row is the camera further down the block
@@ -364,6 +380,19 @@ inline bool bcr_plan_with_order(int nf, const int64_t *keys, size_t nk, const st
             else P.src[((size_t)(m + slot) * cbt + oj) * cbt + oi] = (int32_t)q | BCR_SRC_TRANSPOSED;
         }
     }
+    // pending right-hand-side updates per block (k_bcr_fwd)
+    {
+        std::vector<std::vector<int32_t>> pl(m);
+        for (const BcrOp &op : P.ops) {
+            if (op.kind != 0) continue;
+            pl[op.dst].push_back(op.a0); pl[op.dst].push_back(op.k0);
+            if (op.a1 >= 0) { pl[op.dst].push_back(op.a1); pl[op.dst].push_back(op.k1); }
+        }
+        P.pend_ptr.assign(m + 1, 0);
+        for (int b = 0; b < m; ++b) P.pend_ptr[b + 1] = P.pend_ptr[b] + (int32_t)pl[b].size() / 2;
+        P.pend.clear();
+        for (int b = 0; b < m; ++b) P.pend.insert(P.pend.end(), pl[b].begin(), pl[b].end());
+    }
     P.ok = true;
     return true;
 }
@@ -371,19 +400,34 @@ inline bool bcr_plan_with_order(int nf, const int64_t *keys, size_t nk, const st
 // Plans the elimination for the pattern `keys`: the cameras in index order first (chains and rings as the caller numbered
 // them), else along the chain coordinate of bcr_chain_order, else in reverse Cuthill-McKee order.  false: no order tried makes the pattern a chain / ring with a half
 // bandwidth of at most 21 cameras (or it is too small to bother).
-inline bool bcr_make_plan(int nf, const int64_t *keys, size_t nk, BcrPlan &P) {
+// allow_rest: when no order makes the WHOLE pattern a chain / ring, accept a plan for its in-band part (cameras in
+// index order, else along the chain coordinate) if that part holds at least half of the off-diagonal blocks -- the
+// factorisation of the in-band part then preconditions a CG iteration on the whole system (P.n_rest > 0).
+inline bool bcr_make_plan(int nf, const int64_t *keys, size_t nk, BcrPlan &P, bool allow_rest = false) {
     if (nf < 2) { P = BcrPlan{}; return false; }
-    std::vector<int32_t> order(nf);
+    std::vector<int32_t> order(nf), chain;
     for (int c = 0; c < nf; ++c) order[c] = c;
     if (bcr_plan_with_order(nf, keys, nk, order, P)) return true;
-    if (bcr_chain_order(nf, keys, nk, order) && bcr_plan_with_order(nf, keys, nk, order, P)) {
+    const bool have_chain = bcr_chain_order(nf, keys, nk, chain);
+    if (have_chain && bcr_plan_with_order(nf, keys, nk, chain, P)) {
         P.reordered = true;
         return true;
     }
-    bcr_rcm_order(nf, keys, nk, order);
-    if (!bcr_plan_with_order(nf, keys, nk, order, P)) return false;
-    P.reordered = true;
-    return true;
+    std::vector<int32_t> rcm;
+    bcr_rcm_order(nf, keys, nk, rcm);
+    if (bcr_plan_with_order(nf, keys, nk, rcm, P)) {
+        P.reordered = true;
+        return true;
+    }
+    if (!allow_rest || nf < 2 * BCR_MAX_BAND) return false;
+    const int64_t n_off = (int64_t)nk - nf;   // (every diagonal block is in the pattern)
+    if (bcr_plan_with_order(nf, keys, nk, order, P, true) && 2 * P.n_rest <= n_off) return true;
+    if (have_chain && bcr_plan_with_order(nf, keys, nk, chain, P, true) && 2 * P.n_rest <= n_off) {
+        P.reordered = true;
+        return true;
+    }
+    P = BcrPlan{};
+    return false;
 }
 
 // m diagonal blocks D_k, the coupling slots, and m more blocks for the factors L_k: D_k stays READ-ONLY while a level is
@@ -706,8 +750,9 @@ template <int NT>
 __global__ __launch_bounds__(BA_BCR_BACK_THREADS) void k_bcr_back(const BcrElim *__restrict__ elims, const double *__restrict__ Lf,
                                                   const double *__restrict__ G, double *__restrict__ bv,
                                                   const double *__restrict__ Linv16, const int32_t *__restrict__ pos_f,
-                                                  double *__restrict__ xout) {
+                                                  double *__restrict__ xout, const double *__restrict__ done) {
     constexpr int NB = 16 * NT, PARTS = BA_BCR_BACK_THREADS / NB, RP = (NB + PARTS - 1) / PARTS;
+    if (done && *done != 0.0) return;   // (uniform: queued behind a converged PCG iteration)
     extern __shared__ double bcr_smem[];
     double *sL = bcr_smem;             // NB x NB: L_k (every global load of the kernel is issued up front: the blocked
     double *sLi = sL + NB * NB;        // NT x 256: inverses of its diagonal tiles     substitution below runs out of LDS)
@@ -781,11 +826,92 @@ __global__ __launch_bounds__(BA_BCR_BACK_THREADS) void k_bcr_back(const BcrElim 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ forward (new right-hand side)
+// The factorisation as a PRECONDITIONER: z = M^-1 r for a new right-hand side r through the stored factors -- forward
+// here, then k_bcr_back as it is.  One workgroup per block eliminated at this level:
+//     b_k = r_k - sum over the updates the block has received (W[slot] y_j, the plan's pending list, schedule order),
+//     y_k = L_k^-1 b_k   (blocked substitution out of LDS: y_s = Linv_s b_s per 16-row tile, then the rows below lose it)
+// Every sum has a fixed order (one wave per row of W, DPP tree), so the preconditioner is a fixed linear operator:
+// bit-identical from run to run.  `done` (may be null): the PCG's convergence flag -- a launch queued behind a
+// converged iteration returns at once.
+inline size_t bcr_fwd_lds_bytes(int nt) {
+    const int nb = 16 * nt;
+    return ((size_t)nb * (nb + 1) + (size_t)nt * 256 + nb + 16) * sizeof(double);
+}
+template <int NT>
+__global__ __launch_bounds__(BA_BCR_BACK_THREADS) void k_bcr_fwd(const BcrElim *__restrict__ elims, const int32_t *__restrict__ pend_ptr,
+                                                 const int32_t *__restrict__ pend, const double *__restrict__ Lf,
+                                                 const double *__restrict__ G, double *__restrict__ bv,
+                                                 const double *__restrict__ Linv16, const int32_t *__restrict__ pos_f,
+                                                 const double *__restrict__ rin, const double *__restrict__ done) {
+    constexpr int NB = 16 * NT, LDL = NB + 1, WAVES = BA_BCR_BACK_THREADS / 64, CPL = (NB + 63) / 64;
+    extern __shared__ double bcr_smem[];
+    double *sL = bcr_smem;             // NB x (NB + 1): L_k, a row per lane in the substitution (padded: no bank conflicts)
+    double *sLi = sL + NB * LDL;       // NT x 256: inverses of its diagonal tiles
+    double *srhs = sLi + NT * 256;     // NB
+    double *sx = srhs + NB;            // 16
+    if (done && *done != 0.0) return;
+    const BcrElim el = elims[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const size_t nb2 = (size_t)NB * NB;
+    {
+        const double *L = Lf + el.k * nb2, *li = Linv16 + (size_t)el.k * NT * 256;
+        for (int e = tid; e < NB * NB; e += BA_BCR_BACK_THREADS) {
+            const int r = e / NB, c = e - r * NB;
+            sL[r * LDL + c] = L[e];
+        }
+        for (int e = tid; e < NT * 256; e += BA_BCR_BACK_THREADS) sLi[e] = li[e];
+    }
+    if (tid < NB) {
+        const int fcam = tid < 6 * (NB / 6) ? pos_f[el.k * (NB / 6) + tid / 6] : -1;
+        srhs[tid] = fcam >= 0 ? rin[(size_t)6 * fcam + tid % 6] : 0.0;
+    }
+    __syncthreads();
+    // pending updates: wave wv takes rows wv, wv + WAVES, ...; lanes across the columns
+    const int p0 = pend_ptr[el.k], p1 = pend_ptr[el.k + 1];
+    for (int r = wv; r < NB; r += WAVES) {
+        double sum = 0.0;
+        for (int q = p0; q < p1; ++q) {
+            const double *W = G + (size_t)pend[2 * q] * nb2 + (size_t)r * NB, *y = bv + (size_t)pend[2 * q + 1] * NB;
+            double part = 0.0;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const int col = lane + 64 * c;
+                if (col < NB) part = fma(W[col], y[col], part);
+            }
+            sum += wave_sum_dpp(part);
+        }
+        if (lane == 0 && p1 > p0) srhs[r] -= sum;
+    }
+    __syncthreads();
+    for (int s = 0; s < NT; ++s) {
+        if (tid < 16) {
+            const double *li = sLi + s * 256;   // y_s = Linv_s rhs_s
+            double sum = 0.0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum = fma(li[tid * 16 + r], srhs[16 * s + r], sum);
+            sx[tid] = sum;
+        }
+        __syncthreads();
+        if (tid >= 16 * s + 16 && tid < NB) {
+            double sum = 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sum = fma(sL[tid * LDL + 16 * s + i], sx[i], sum);
+            srhs[tid] -= sum;
+        } else if (tid >= 16 * s && tid < 16 * s + 16) {
+            srhs[tid] = sx[tid - 16 * s];
+        }
+        __syncthreads();
+    }
+    if (tid < NB) bv[(size_t)el.k * NB + tid] = srhs[tid];
+}
+
 // ------------------------------------------------------------------------------------------------ launch
 struct BcrDev {
     const BcrElim *elims;
     const BcrOp *ops;
     const int32_t *src, *pos_f;
+    const int32_t *pend_ptr, *pend;   // forward substitution of a new right-hand side (k_bcr_fwd)
     double *DG;      // bcr_matrix_doubles: m diagonal blocks, the coupling slots, then the m factors L_k
     double *bv;      // bcr_vec_doubles
     double *linv;    // bcr_linv_doubles
@@ -796,6 +922,9 @@ template <int NT>
 inline hipError_t bcr_set_attr() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bcr_factor<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)bcr_factor_lds_bytes(NT));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bcr_fwd<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)bcr_fwd_lds_bytes(NT));
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void *>(k_bcr_back<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)bcr_back_lds_bytes(NT));
@@ -832,9 +961,37 @@ inline hipError_t bcr_solve_launch_t(hipStream_t st, const BcrPlan &P, const Bcr
     }
     for (int l = nl - 1; l >= 0; --l) {
         const int ne_l = P.lvl_elim[l + 1] - P.lvl_elim[l];
-        hipLaunchKernelGGL(k_bcr_back<NT>, dim3(ne_l), dim3(BA_BCR_BACK_THREADS), bcr_back_lds_bytes(NT), st, d.elims + P.lvl_elim[l], Lf, G, d.bv, d.linv, d.pos_f, x);
+        hipLaunchKernelGGL(k_bcr_back<NT>, dim3(ne_l), dim3(BA_BCR_BACK_THREADS), bcr_back_lds_bytes(NT), st, d.elims + P.lvl_elim[l], Lf, G, d.bv, d.linv, d.pos_f, x, (const double *)nullptr);
     }
     return hipGetLastError();
+}
+
+// z = M^-1 r through the factors of the last bcr_solve_launch (r, z: vectors over the free cameras)
+template <int NT>
+inline hipError_t bcr_apply_launch_t(hipStream_t st, const BcrPlan &P, const BcrDev &d, const double *r, double *z, const double *done) {
+    constexpr int NB = 16 * NT;
+    const size_t nb2 = (size_t)NB * NB;
+    double *G = d.DG + (size_t)P.m * nb2, *Lf = G + (size_t)P.n_slots * nb2;
+    const int nl = P.levels();
+    for (int l = 0; l < nl; ++l) {
+        const int ne_l = P.lvl_elim[l + 1] - P.lvl_elim[l];
+        hipLaunchKernelGGL(k_bcr_fwd<NT>, dim3(ne_l), dim3(BA_BCR_BACK_THREADS), bcr_fwd_lds_bytes(NT), st, d.elims + P.lvl_elim[l], d.pend_ptr,
+                           d.pend, Lf, G, d.bv, d.linv, d.pos_f, r, done);
+    }
+    for (int l = nl - 1; l >= 0; --l) {
+        const int ne_l = P.lvl_elim[l + 1] - P.lvl_elim[l];
+        hipLaunchKernelGGL(k_bcr_back<NT>, dim3(ne_l), dim3(BA_BCR_BACK_THREADS), bcr_back_lds_bytes(NT), st, d.elims + P.lvl_elim[l], Lf, G, d.bv, d.linv, d.pos_f, z, done);
+    }
+    return hipGetLastError();
+}
+inline hipError_t bcr_apply_launch(hipStream_t st, const BcrPlan &P, const BcrDev &d, const double *r, double *z, const double *done) {
+    switch (P.nt) {
+        case 2: return bcr_apply_launch_t<2>(st, P, d, r, z, done);
+        case 4: return bcr_apply_launch_t<4>(st, P, d, r, z, done);
+        case 6: return bcr_apply_launch_t<6>(st, P, d, r, z, done);
+        case 8: return bcr_apply_launch_t<8>(st, P, d, r, z, done);
+    }
+    return hipErrorInvalidValue;
 }
 
 // x = -S^-1 g; *d.info (device) = 0 on success, else 1 + the block whose factorisation met a non-positive pivot

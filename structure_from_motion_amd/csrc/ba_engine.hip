@@ -344,16 +344,23 @@ struct BaHandle {
     int bcr_state = 0;                                 //   0 not planned yet, 1 usable, -1 the pattern is no chain / ring
     DevBuf<int32_t> bcr_tab;                           //   elimination / update / block tables
     DevBuf<double> bcr_dg, bcr_bv, bcr_linv;           //   diagonal blocks + coupling slots, block vectors, tile inverses
-    size_t bcr_off[4] = {0, 0, 0, 0};                  //   offsets of the tables inside bcr_tab
+    size_t bcr_off[6] = {0, 0, 0, 0, 0, 0};            //   offsets of the tables inside bcr_tab
     DevBuf<long long> upper_keys;
     DevBuf<int> dense_info;
     int dense_fallbacks = 0;
+    // AUTO between the blocked dense Cholesky and block-Jacobi PCG on a (nearly) full pattern: both are timed once, then
+    // the faster one is kept (do_step)
+    int auto_phase = 0;            // 0: time the direct solver next, 1: time PCG next, 2: decided
+    bool auto_use_pcg = false;
+    float auto_ms_direct = 0.f, auto_ms_pcg = 0.f;
+    int auto_pcg_iters = 0;
     bool dense_attr_set = false;
     DevBuf<LmState> state;
     LmState hstate{};
     LmState *hstate_pinned = nullptr;   // page-locked landing place of read_state
     PcgScalars hpcg{};
     PcgScalars *hpcg_pinned = nullptr;   // page-locked landing place of the PCG's convergence poll
+    int *dense_info_pinned = nullptr;    // ... and of the pivot flag of the preconditioner's factorisation (do_bcr_pcg)
     // collectives
     BaCollectiveFn coll = nullptr;
     void *coll_user = nullptr;
@@ -377,6 +384,7 @@ struct BaHandle {
         if (ev3) (void)hipEventDestroy(ev3);
         if (hstate_pinned) (void)hipHostFree(hstate_pinned);
         if (hpcg_pinned) (void)hipHostFree(hpcg_pinned);
+        if (dense_info_pinned) (void)hipHostFree(dense_info_pinned);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -682,7 +690,8 @@ int bcr_plan_for(BaHandle *h) {
     const Symbolic &s = h->sym;
     h->bcr_state = -1;
     try {
-        if (!bcr_make_plan(s.n_free, s.upper_keys.data(), s.upper_keys.size(), h->bcr_plan)) return BA_OK;
+        // (a plan for the in-band part only -- a chain / ring plus a remainder -- is accepted too: do_bcr_pcg)
+        if (!bcr_make_plan(s.n_free, s.upper_keys.data(), s.upper_keys.size(), h->bcr_plan, true)) return BA_OK;
     } catch (const std::bad_alloc &) {
         return fail(BA_ERR_NOMEM, "out of host memory while planning the cyclic reduction");
     }
@@ -698,6 +707,8 @@ int bcr_plan_for(BaHandle *h) {
     h->bcr_off[1] = put(P.ops.data(), P.ops.size() * sizeof(BcrOp) / 4);
     h->bcr_off[2] = put(P.src.data(), P.src.size());
     h->bcr_off[3] = put(P.pos_f.data(), P.pos_f.size());
+    h->bcr_off[4] = put(P.pend_ptr.data(), P.pend_ptr.size());
+    h->bcr_off[5] = put(P.pend.data(), P.pend.size());
     HIPCHK(h->bcr_tab.upload(tab, h->stream));
     HIPCHK(h->bcr_dg.alloc(bcr_matrix_doubles(P)));
     HIPCHK(h->bcr_bv.alloc(bcr_vec_doubles(P)));
@@ -707,19 +718,83 @@ int bcr_plan_for(BaHandle *h) {
     h->bcr_state = 1;
     return BA_OK;
 }
-int do_bcr(BaHandle *h, bool *launched) {
-    *launched = false;
-    if (h->sym.n_free == 0 || h->bcr_state != 1) return BA_OK;
-    *launched = true;
+BcrDev bcr_dev(BaHandle *h) {
     const int32_t *t = h->bcr_tab.p;
     BcrDev d{};
     d.elims = reinterpret_cast<const BcrElim *>(t + h->bcr_off[0]);
     d.ops = reinterpret_cast<const BcrOp *>(t + h->bcr_off[1]);
     d.src = t + h->bcr_off[2];
     d.pos_f = t + h->bcr_off[3];
+    d.pend_ptr = t + h->bcr_off[4];
+    d.pend = t + h->bcr_off[5];
     d.DG = h->bcr_dg.p; d.bv = h->bcr_bv.p; d.linv = h->bcr_linv.p; d.info = h->dense_info.p;
-    HIPCHK(bcr_solve_launch(h->stream, h->bcr_plan, d, h->S, h->gred, h->px.p));
+    return d;
+}
+int do_bcr(BaHandle *h, bool *launched) {
+    *launched = false;
+    if (h->sym.n_free == 0 || h->bcr_state != 1) return BA_OK;
+    *launched = true;
+    HIPCHK(bcr_solve_launch(h->stream, h->bcr_plan, bcr_dev(h), h->S, h->gred, h->px.p));
     return BA_OK;  // (pivot flag: see do_step)
+}
+
+// A chain / ring PLUS a remainder (a revisit, a few long tracks; bcr_plan.n_rest > 0): CG on the whole S,
+// preconditioned by the cyclic-reduction factorisation of its in-band part M.  The factorisation is computed once per
+// step together with z0 = M^-1 (-g) (the direct solver's own launch sequence); every further iteration applies the
+// stored factors to the new residual (k_bcr_fwd per level, then k_bcr_back per level).  Block-Jacobi PCG needs
+// hundreds of iterations on such a chain (its low-frequency modes); with M they are solved exactly and what is left
+// for CG is the remainder.  Result in h->px; *ok = false when the factorisation of M met a bad pivot (M is S without
+// some off-diagonal blocks: not necessarily positive definite) -- the caller falls back to block-Jacobi PCG.
+int do_bcr_pcg(BaHandle *h, int *iters_out, bool *ok) {
+    hipStream_t st = h->stream;
+    const int nf = h->sym.n_free;
+    *iters_out = 0;
+    *ok = true;
+    if (nf == 0) return BA_OK;
+    const int nb_cam = (nf + 255) / 256, nb_row = (nf + 3) / 4;
+    const BcrDev d = bcr_dev(h);
+    HIPCHK(bcr_solve_launch(st, h->bcr_plan, d, h->S, h->gred, h->pz.p));   // factors of M, z0 = M^-1 (-g)
+    HIPCHK(hipMemsetAsync(h->pcg_sc.p, 0, sizeof(PcgScalars), st));
+    PcgPartials pp{};
+    {
+        HIPCHK(h->pcg_part.alloc_grow((size_t)7 * nb_cam + (size_t)2 * nb_row));
+        double *q = h->pcg_part.p;
+        for (int k = 0; k < 3; ++k) { pp.rz[k] = q; q += nb_cam; pp.rn[k] = q; q += nb_cam; }
+        pp.bb = q; q += nb_cam;
+        pp.pq[0] = q; pp.pq[1] = q + nb_row;
+        pp.nb_cam = nb_cam; pp.nb_row = nb_row;
+    }
+    hipLaunchKernelGGL(k_pcgx_init, dim3(nb_cam), dim3(256), 0, st, nf, h->gred, h->pz.p, h->px.p, h->pr.p, pp);
+    const double tol2 = h->opt.pcg_tol * h->opt.pcg_tol;
+    const int max_it = h->opt.pcg_max_iter > 0 ? h->opt.pcg_max_iter : 500;
+    const double *done = &h->pcg_sc.p->done;
+    if (!h->hpcg_pinned) HIPCHK(hipHostMalloc((void **)&h->hpcg_pinned, sizeof(PcgScalars), hipHostMallocDefault));
+    if (h->dense_info_pinned == nullptr) HIPCHK(hipHostMalloc((void **)&h->dense_info_pinned, sizeof(int), hipHostMallocDefault));
+    const int batch = 2;   // (an iteration is some twenty launches: poll the convergence flag often)
+    int it = 0;
+    while (it < max_it) {
+        const int end = std::min(max_it, it + batch);
+        for (; it < end; ++it) {
+            double *p_in = (it & 1) ? h->pq.p : h->pp.p, *p_out = (it & 1) ? h->pp.p : h->pq.p;
+            hipLaunchKernelGGL(k_pcg_a, dim3(nb_row), dim3(256), 0, st, nf, it, tol2, h->bsr_row.p, h->bsr_col.p,
+                               h->bsr_src.p, h->S, h->pz.p, p_in, p_out, h->pqv.p, h->pcg_sc.p, pp);
+            hipLaunchKernelGGL(k_pcg_b, dim3(nb_cam), dim3(256), 0, st, nf, it, (const double *)nullptr, p_out, h->pqv.p, h->px.p,
+                               h->pr.p, h->pz.p, h->pcg_sc.p, pp);
+            HIPCHK(bcr_apply_launch(st, h->bcr_plan, d, h->pr.p, h->pz.p, done));
+            hipLaunchKernelGGL(k_pcgx_dot, dim3(nb_cam), dim3(256), 0, st, nf, it, h->pr.p, h->pz.p, h->pcg_sc.p, pp);
+        }
+        HIPCHK(hipMemcpyAsync(h->hpcg_pinned, h->pcg_sc.p, sizeof(PcgScalars), hipMemcpyDeviceToHost, st));
+        if (it <= batch) HIPCHK(hipMemcpyAsync(h->dense_info_pinned, h->dense_info.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        h->hpcg = *h->hpcg_pinned;
+        if (it <= batch && *h->dense_info_pinned != 0) {   // the factorisation of M failed: not a preconditioner
+            *ok = false;
+            return BA_OK;
+        }
+        if (h->hpcg.done != 0.0) break;
+    }
+    *iters_out = (int)h->hpcg.iters;
+    return BA_OK;
 }
 
 // the part of a trial step behind the linear solve: camera update, back-substitution + trial cost, reductions, decision
@@ -793,14 +868,32 @@ int do_step(BaHandle *h) {
         if ((e = bcr_plan_for(h))) return e;
         can_bcr = h->bcr_state == 1;
     }
+    // A plan with a remainder (chain / ring plus a few far-apart pairs) is no direct solver: it preconditions CG (do_bcr_pcg)
+    const bool bcr_rest = can_bcr && h->bcr_plan.n_rest > 0;
+    // AUTO on a (nearly) full pattern beyond the one-workgroup solver: blocked dense Cholesky or block-Jacobi PCG, whichever
+    // is faster HERE -- the dense solve costs n^3 / 3 whatever the problem, PCG costs its iteration count, which depends on
+    // the conditioning (object-centric captures: a few dozen iterations).  Both are timed once with events on the stream
+    // (the step's one host synchronisation is there anyway), then the faster one is kept; PCG is timed again when its
+    // iteration count has grown by half.
+    const bool auto_pick = ls == BA_SOLVER_AUTO && !can_dense && !can_bcr && !can_band && can_big && dense_pattern;
+    bool time_direct = false, time_pcg = false, skip_direct = false;
+    if (auto_pick) {
+        if (h->auto_phase == 0) time_direct = true;
+        else if (h->auto_phase == 1) { time_pcg = true; skip_direct = true; }
+        else skip_direct = h->auto_use_pcg;
+    }
     if ((ls == BA_SOLVER_AUTO || ls == BA_SOLVER_DENSE_CHOLESKY) && can_dense) {
         if ((e = do_dense(h, &direct))) return e;
-    } else if (can_bcr) {
+    } else if (can_bcr && !bcr_rest) {
         if ((e = do_bcr(h, &direct))) return e;
+    } else if (bcr_rest) {
+        // (iterative: below)
     } else if ((ls == BA_SOLVER_AUTO || ls == BA_SOLVER_BANDED_CHOLESKY) && can_band) {
         if ((e = do_banded(h, &direct))) return e;
-    } else if (can_big && (ls == BA_SOLVER_DENSE_CHOLESKY || (ls == BA_SOLVER_AUTO && dense_pattern))) {
+    } else if (can_big && !skip_direct && (ls == BA_SOLVER_DENSE_CHOLESKY || (ls == BA_SOLVER_AUTO && dense_pattern))) {
+        if (time_direct) HIPCHK(hipEventRecord(h->ev2, h->stream));
         if ((e = do_dense_big(h, &direct))) return e;
+        if (time_direct) HIPCHK(hipEventRecord(h->ev3, h->stream));
     }
     if (direct) {
         // The direct solvers leave a pivot flag on the device.  The rest of the step is queued behind them without
@@ -812,13 +905,40 @@ int do_step(BaHandle *h) {
         if ((e = read_state(h))) return e;  // (k_decide copies the flag into the state: one copy brings both)
         const int info = h->hstate.solve_info;
         if (h->opt.verbose >= 3) { fprintf(stderr, "[ba_hip r%d] direct solve info=%d\n", h->rank, info); fflush(stderr); }
+        if (time_direct) {
+            if (hipEventElapsedTime(&h->auto_ms_direct, h->ev2, h->ev3) != hipSuccess) h->auto_ms_direct = 0.f;
+            h->auto_phase = 1;
+        }
         if (info == 0) {
             if (h->hstate.accept) h->cur ^= 1;
             return BA_OK;
         }
         h->dense_fallbacks++;
     }
-    if ((e = do_pcg(h, &pcg_it))) return e;
+    bool solved = false;
+    if (bcr_rest && !getenv("BA_DEBUG_FAIL_DIRECT")) {
+        if ((e = do_bcr_pcg(h, &pcg_it, &solved))) return e;
+        if (!solved) h->dense_fallbacks++;
+    }
+    if (!solved) {
+        if (time_pcg) HIPCHK(hipEventRecord(h->ev2, h->stream));
+        if ((e = do_pcg(h, &pcg_it))) return e;
+        if (time_pcg) {
+            HIPCHK(hipEventRecord(h->ev3, h->stream));
+            HIPCHK(hipEventSynchronize(h->ev3));
+            if (hipEventElapsedTime(&h->auto_ms_pcg, h->ev2, h->ev3) != hipSuccess) h->auto_ms_pcg = 0.f;
+            const int max_it = h->opt.pcg_max_iter > 0 ? h->opt.pcg_max_iter : 500;
+            h->auto_pcg_iters = pcg_it;
+            // (a PCG that ran into its iteration cap did not solve the system: never the choice)
+            h->auto_use_pcg = pcg_it < max_it && h->auto_ms_pcg > 0.f && h->auto_ms_direct > 0.f && h->auto_ms_pcg < h->auto_ms_direct;
+            h->auto_phase = 2;
+            if (h->opt.verbose >= 2)
+                printf("[ba_hip] AUTO on a full pattern: blocked dense Cholesky %.2f ms, block-Jacobi PCG %.2f ms (%d iterations) -> %s\n",
+                       h->auto_ms_direct, h->auto_ms_pcg, pcg_it, h->auto_use_pcg ? "PCG" : "dense");
+        } else if (auto_pick && h->auto_phase == 2 && h->auto_use_pcg && 2 * pcg_it > 3 * h->auto_pcg_iters + 20) {
+            h->auto_phase = 1;   // the system has become harder for PCG: time it again next step
+        }
+    }
     h->total_pcg += pcg_it;
     if ((e = step_tail(h, nullptr))) return e;
     if ((e = read_state(h))) return e;
@@ -864,6 +984,7 @@ int upload_values(BaHandle *h, const HostProblem &hp) {
     h->cur = 0;
     h->total_pcg = 0;
     h->dense_fallbacks = 0;
+    h->auto_phase = 0;
     h->initial_cost = NAN;
     h->built = false;
     HIPCHK(hipMemcpyAsync(h->state.p, &h->hstate, sizeof(LmState), hipMemcpyHostToDevice, st));
@@ -1297,7 +1418,8 @@ int ba_append(BaHandle *h, const BaProblem *grown, const BaOptions *opt, int32_t
     }
 }
 
-int ba_bcr_plan(int32_t n_free, const int32_t *pairs, int64_t n_pairs, int32_t *out, int64_t capacity, int64_t *needed) {
+static int bcr_plan_serialise(int32_t n_free, const int32_t *pairs, int64_t n_pairs, bool allow_rest, int32_t *out, int64_t capacity,
+                              int64_t *needed) {
     if (!needed || n_pairs < 0 || (n_pairs > 0 && !pairs) || n_free < 0) return fail(BA_ERR_INVALID, "bad argument");
     try {
         std::vector<int64_t> keys;
@@ -1311,8 +1433,9 @@ int ba_bcr_plan(int32_t n_free, const int32_t *pairs, int64_t n_pairs, int32_t *
         std::sort(keys.begin(), keys.end());
         keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
         BcrPlan P;
-        const bool ok = bcr_make_plan(n_free, keys.data(), keys.size(), P);
-        std::vector<int32_t> w = {ok ? 1 : 0, (P.cyclic ? 1 : 0) | (P.reordered ? 2 : 0), P.m, P.nt, P.nb, P.n_slots, P.n_init_slots, ok ? P.levels() : 0};
+        const bool ok = bcr_make_plan(n_free, keys.data(), keys.size(), P, allow_rest);
+        std::vector<int32_t> w = {ok ? 1 : 0, (P.cyclic ? 1 : 0) | (P.reordered ? 2 : 0) | (P.n_rest > 0 ? 4 : 0), P.m, P.nt, P.nb, P.n_slots,
+                                  P.n_init_slots, ok ? P.levels() : 0};
         if (ok) {
             // src refers to the position of a pair in the SORTED UNIQUE list = the block order of S
             w.insert(w.end(), P.blk_start.begin(), P.blk_start.end());
@@ -1322,6 +1445,9 @@ int ba_bcr_plan(int32_t n_free, const int32_t *pairs, int64_t n_pairs, int32_t *
             w.insert(w.end(), P.lvl_op.begin(), P.lvl_op.end());
             for (const BcrElim &e : P.elims) w.insert(w.end(), {e.k, e.gu, e.gv, e.u, e.v});
             for (const BcrOp &o : P.ops) w.insert(w.end(), {o.kind, o.dst, o.a0, o.b0, o.a1, o.b1, o.k0, o.k1, o.init});
+            w.push_back((int32_t)std::min<int64_t>(P.n_rest, INT32_MAX));
+            w.insert(w.end(), P.pend_ptr.begin(), P.pend_ptr.end());
+            w.insert(w.end(), P.pend.begin(), P.pend.end());
         }
         *needed = (int64_t)w.size();
         if (out) {
@@ -1332,6 +1458,13 @@ int ba_bcr_plan(int32_t n_free, const int32_t *pairs, int64_t n_pairs, int32_t *
     } catch (const std::bad_alloc &) {
         return fail(BA_ERR_NOMEM, "out of host memory");
     }
+}
+
+int ba_bcr_plan(int32_t n_free, const int32_t *pairs, int64_t n_pairs, int32_t *out, int64_t capacity, int64_t *needed) {
+    return bcr_plan_serialise(n_free, pairs, n_pairs, false, out, capacity, needed);
+}
+int ba_bcr_plan_rest(int32_t n_free, const int32_t *pairs, int64_t n_pairs, int32_t *out, int64_t capacity, int64_t *needed) {
+    return bcr_plan_serialise(n_free, pairs, n_pairs, true, out, capacity, needed);
 }
 
 int ba_get_pattern(BaHandle *h, int32_t *out_pairs, int64_t capacity, int64_t *n_pairs) {

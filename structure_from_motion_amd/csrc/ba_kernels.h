@@ -962,22 +962,64 @@ __global__ __launch_bounds__(256) void k_pcg_b(int nf, int it, const double *__r
             r[i] = rv[b];
             rn += rv[b] * rv[b];
         }
+        if (Minv) {   // block-Jacobi: z = M^-1 r here; another preconditioner (do_bcr_pcg): z and r.z by the kernels that follow
 #pragma unroll
-        for (int a = 0; a < 6; ++a) {
-            double zz = 0.0;
+            for (int a = 0; a < 6; ++a) {
+                double zz = 0.0;
 #pragma unroll
-            for (int b = 0; b < 6; ++b) zz += Minv[(size_t)f * 36 + a * 6 + b] * rv[b];
-            z[(size_t)f * 6 + a] = zz;
-            rz += rv[a] * zz;
+                for (int b = 0; b < 6; ++b) zz += Minv[(size_t)f * 36 + a * 6 + b] * rv[b];
+                z[(size_t)f * 6 + a] = zz;
+                rz += rv[a] * zz;
+            }
         }
     }
     rz = block_sum256(rz, red);
     rn = block_sum256(rn, red);
-    if (threadIdx.x == 0) { pp.rz[(it + 1) % 3][blockIdx.x] = rz; pp.rn[(it + 1) % 3][blockIdx.x] = rn; }
+    if (threadIdx.x == 0) {
+        if (Minv) pp.rz[(it + 1) % 3][blockIdx.x] = rz;
+        pp.rn[(it + 1) % 3][blockIdx.x] = rn;
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         sc->iters = it + 1;
         if (!(pqv > 0.0)) sc->done = 1.0;  // S p . p <= 0: stop (x keeps the last good iterate)
     }
+}
+
+// PCG with a preconditioner of its own (the cyclic reduction of the in-band part of S, do_bcr_pcg):
+//   k_pcgx_init: x = 0, r = -g_red, and with z = M^-1 r already there: r.z and |r|^2 into the partials of slot 0
+//   k_pcgx_dot:  r.z of iteration it + 1 once z = M^-1 r has been applied
+__global__ __launch_bounds__(256) void k_pcgx_init(int nf, const double *__restrict__ gred, const double *__restrict__ z,
+                                                   double *__restrict__ x, double *__restrict__ r, PcgPartials pp) {
+    __shared__ double red[4];
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    double rz = 0.0, bb = 0.0;
+    if (f < nf) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            const size_t i = (size_t)f * 6 + a;
+            const double rv = -gred[i];
+            x[i] = 0.0;
+            r[i] = rv;
+            rz += rv * z[i];
+            bb += rv * rv;
+        }
+    }
+    rz = block_sum256(rz, red);
+    bb = block_sum256(bb, red);
+    if (threadIdx.x == 0) { pp.rz[0][blockIdx.x] = rz; pp.bb[blockIdx.x] = bb; pp.rn[0][blockIdx.x] = bb; }
+}
+__global__ __launch_bounds__(256) void k_pcgx_dot(int nf, int it, const double *__restrict__ r, const double *__restrict__ z,
+                                                  const PcgScalars *sc, PcgPartials pp) {
+    __shared__ double red[4];
+    if (sc->done != 0.0) return;
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    double rz = 0.0;
+    if (f < nf) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) rz += r[(size_t)f * 6 + a] * z[(size_t)f * 6 + a];
+    }
+    rz = block_sum256(rz, red);
+    if (threadIdx.x == 0) pp.rz[(it + 1) % 3][blockIdx.x] = rz;
 }
 
 // ------------------------------------------------------------------ trial cameras

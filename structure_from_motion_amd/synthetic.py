@@ -70,8 +70,27 @@ def _finish(rng, cam_pose_gt, cam_intr, points_gt, obs_cam, obs_pt, noise, outli
                 cam_pose_gt=cam_pose_gt, points_gt=points_gt)
 
 
+def _revisits(rng, n_cams, obs_cam, obs_pt, first_cam, frac, length, ring):
+    """A fraction of the points is seen a SECOND time by ``length`` consecutive cameras far away along the trajectory (a
+    revisit / loop closure in the middle of a sequence, landmarks seen again from another street): the co-visibility
+    pattern is then a chain (or ring) plus a remainder of far-apart camera pairs."""
+    n_points = len(first_cam)
+    pick = np.flatnonzero(rng.random(n_points) < frac)
+    lo, hi = max(n_cams // 8, 2 * length + 44), max(n_cams // 2, 2 * length + 45)
+    off = rng.integers(lo, hi, size=len(pick)) * rng.choice([-1, 1], size=len(pick))
+    start = first_cam[pick] + off
+    start = start % n_cams if ring else np.clip(start, 0, n_cams - length)
+    extra_pt = np.repeat(pick, length)
+    extra_cam = np.repeat(start, length) + np.tile(np.arange(length), len(pick))
+    if ring:
+        extra_cam %= n_cams
+    key = np.unique(np.concatenate([obs_pt * n_cams + obs_cam, extra_pt * n_cams + extra_cam]))   # (no duplicate observation)
+    return key % n_cams, key // n_cams
+
+
 def make_street(n_cams, n_points, n_obs, seed=0, noise=0.5, outlier_frac=0.01, max_track=16,
-                n_fixed=2, sig_r=1e-3, sig_t=1e-2, sig_p_rel=1e-2, point_offset=0, cam_seed=None):
+                n_fixed=2, sig_r=1e-3, sig_t=1e-2, sig_p_rel=1e-2, point_offset=0, cam_seed=None,
+                revisit_frac=0.0, revisit_len=3):
     """BAL-shaped problem: cameras on a street trajectory (baseline 1), points in a slab at
     depth 5..50 baselines, each observed by a contiguous window of cameras whose length follows
     2 + Poisson so that the mean track is n_obs / n_points.  ``cam_seed`` fixes the cameras
@@ -101,6 +120,8 @@ def make_street(n_cams, n_points, n_obs, seed=0, noise=0.5, outlier_frac=0.01, m
     first = np.cumsum(L) - L
     within = np.arange(len(obs_pt), dtype=np.int64) - np.repeat(first, L)
     obs_cam = np.repeat(start, L) + within
+    if revisit_frac > 0:
+        obs_cam, obs_pt = _revisits(rng, n_cams, obs_cam, obs_pt, start, revisit_frac, revisit_len, ring=False)
     cam_fixed = np.zeros(n_cams, dtype=np.uint8)
     cam_fixed[:n_fixed] = 1
     prob = _finish(rng, cam_pose_gt, cam_intr, points_gt, obs_cam, obs_pt, noise, outlier_frac,
@@ -112,7 +133,7 @@ def make_street(n_cams, n_points, n_obs, seed=0, noise=0.5, outlier_frac=0.01, m
 def make_ring(n_cams, n_points, seed=0, K=(1520.4, 1525.9, 302.32, 246.87), focal_jitter=0.02,
               noise=0.35, outlier_frac=0.0, visibility="dense", mean_track=4.0, n_fixed=1,
               n_seed_points=None, radius=4.0, sig_r=1e-3, sig_t=1e-2, sig_p=1e-2, n_unobserved=0,
-              max_track=24, n_landmarks=0, point_radius=None):
+              max_track=24, n_landmarks=0, point_radius=None, revisit_frac=0.0, revisit_len=3):
     """Temple / Fountain-shaped problem: cameras on a ring (or arc) of ``radius`` looking at a
     unit blob of points.
 
@@ -161,6 +182,8 @@ def make_ring(n_cams, n_points, seed=0, K=(1520.4, 1525.9, 302.32, 246.87), foca
         else:
             start = np.clip(start, 0, n_cams - L)
             obs_cam = np.repeat(start, L) + within
+        if revisit_frac > 0:
+            obs_cam, obs_pt = _revisits(rng, n_cams, obs_cam, obs_pt, start % n_cams, revisit_frac, revisit_len, ring=n_cams > 12)
     elif visibility == "random":
         # object-centric capture: every point is seen by a random set of cameras from all around the ring (mean length
         # ``mean_track``) -- any two cameras share landmarks, the reduced camera system is (nearly) full
@@ -221,6 +244,13 @@ def make_config(name, seed=None, scale=1.0):
         return make_ring(1778, int(150000 * scale), seed=1239 if seed is None else seed, K=(1200.0, 1200.0, 960.0, 540.0),
                          focal_jitter=0.05, noise=0.5, outlier_frac=0.01, mean_track=8.0, max_track=40, n_fixed=2,
                          radius=283.0, point_radius=(4.0, 30.0), sig_t=2e-2, sig_p=5e-2)
+    if name == "ring1778_revisit":
+        # the closed ring above with 1 % of its points seen a second time from far away along the ring (revisits): a ring
+        # PLUS a remainder of far-apart camera pairs -- no direct solver of the engine applies; AUTO = CG preconditioned by
+        # the cyclic reduction of the in-band part
+        return make_ring(1778, int(150000 * scale), seed=1239 if seed is None else seed, K=(1200.0, 1200.0, 960.0, 540.0),
+                         focal_jitter=0.05, noise=0.5, outlier_frac=0.01, mean_track=8.0, max_track=40, n_fixed=2,
+                         radius=283.0, point_radius=(4.0, 30.0), sig_t=2e-2, sig_p=5e-2, revisit_frac=0.01, revisit_len=3)
     if name == "orbit1024":
         # object-centric: 1024 cameras around one object, every point seen from all around -- S is full (6132 unknowns):
         # AUTO's blocked dense Cholesky (ba_dense_big.h), the "genuine dense contraction" of BASELINE.json's north_star

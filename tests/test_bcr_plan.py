@@ -57,7 +57,8 @@ def _gather(plan, blocks):
     return out
 
 
-def _execute(plan, blocks, g):
+def _execute(plan, blocks, g, keep=None):
+    """The factorisation + solve as the fused launch sequence does it; ``keep`` (a dict) receives the factors."""
     m, nb = plan["m"], plan["nb"]
     init = _gather(plan, blocks)
     D = [np.tril(init[b]) + np.tril(init[b], -1).T for b in range(m)]          # the kernels read the lower triangle
@@ -99,7 +100,39 @@ def _execute(plan, blocks, g):
             for o, f in enumerate(plan["pos_f"][k]):
                 if f >= 0:
                     x[6 * f:6 * f + 6] = bv[k][6 * o:6 * o + 6]
+    if keep is not None:
+        keep.update(L=L, G=G)
     return x
+
+
+def _apply(plan, keep, r):
+    """z = M^-1 r through the stored factors, as k_bcr_fwd / k_bcr_back do it: forward with the plan's pending lists (a
+    block subtracts every update it has received when it is eliminated), then backward level by level."""
+    m, nb = plan["m"], plan["nb"]
+    L, G = keep["L"], keep["G"]
+    bv = np.zeros((m, nb))
+    for lv in range(plan["levels"]):
+        for k, gu, gv, u, v in plan["elims"][plan["lvl_elim"][lv]:plan["lvl_elim"][lv + 1]]:
+            b = np.zeros(nb)
+            for o, f in enumerate(plan["pos_f"][k]):
+                if f >= 0:
+                    b[6 * o:6 * o + 6] = r[6 * f:6 * f + 6]
+            for slot, j in plan["pend"][plan["pend_ptr"][k]:plan["pend_ptr"][k + 1]]:
+                b -= G[slot] @ bv[j]
+            bv[k] = np.linalg.solve(L[k], b)
+    z = np.zeros(len(r))
+    for lv in range(plan["levels"] - 1, -1, -1):
+        for k, gu, gv, u, v in plan["elims"][plan["lvl_elim"][lv]:plan["lvl_elim"][lv + 1]]:
+            t = bv[k].copy()
+            if gu >= 0:
+                t -= G[gu].T @ bv[u]
+            if gv >= 0:
+                t -= G[gv].T @ bv[v]
+            bv[k] = np.linalg.solve(L[k].T, t)
+            for o, f in enumerate(plan["pos_f"][k]):
+                if f >= 0:
+                    z[6 * f:6 * f + 6] = bv[k][6 * o:6 * o + 6]
+    return z
 
 
 CASES = [(12, 2, 0), (40, 3, 0), (41, 5, 0), (64, 5, 1), (37, 4, 1), (100, 8, 0), (90, 9, 1), (70, 15, 0), (113, 16, 0),
@@ -123,9 +156,14 @@ def test_schedule_solves_the_system(nf, band, ring):
     assert sorted(ks.tolist()) == list(range(plan["m"]))
     assert plan["lvl_elim"][-1] - plan["lvl_elim"][-2] == 1 and tuple(plan["elims"][-1, 1:]) == (-1, -1, -1, -1)
     assert plan["levels"] <= int(np.ceil(np.log2(plan["m"]))) + 1
-    x = _execute(plan, blocks, g)
+    keep = {}
+    x = _execute(plan, blocks, g, keep)
     want = np.linalg.solve(A, -g)
     np.testing.assert_allclose(x, want, rtol=0, atol=1e-13 * max(1.0, np.abs(want).max()) * 10)
+    # a NEW right-hand side through the stored factors (the preconditioner path: forward by pending lists, then backward)
+    r = np.random.default_rng(nf).uniform(-1.0, 1.0, size=6 * nf)
+    assert plan["n_rest"] == 0
+    np.testing.assert_allclose(_apply(plan, keep, r), np.linalg.solve(A, r), rtol=0, atol=1e-12)
 
 
 @pytest.mark.parametrize("nf,band", [(60, 3), (150, 7), (200, 10), (97, 2)])
@@ -174,3 +212,74 @@ def test_patterns_without_a_schedule():
     assert _capi.bcr_plan(1, np.array([(0, 0)], dtype=np.int32)) is None
     with pytest.raises(_capi.BaError):
         _capi.bcr_plan(4, np.array([(0, 7)], dtype=np.int32))       # index out of range
+
+
+@pytest.mark.parametrize("nf,band,ring,n_far", [(120, 6, 0, 15), (300, 12, 1, 60), (500, 20, 1, 200)])
+def test_chain_plus_remainder_gets_a_preconditioner(nf, band, ring, n_far):
+    """A chain / ring plus far-apart pairs (revisits): no exact schedule, but ``ba_bcr_plan_rest`` plans the in-band part.
+    Executed with NumPy, the plan factors exactly the in-band matrix M (the far blocks appear in no table), and its
+    forward / backward substitution applies M^-1 to any right-hand side; CG on the whole matrix preconditioned by it
+    converges in a handful of iterations where unpreconditioned CG needs many."""
+    pairs, blocks, A, g = _system(nf, band, bool(ring), seed=7 * nf + band)
+    rng = np.random.default_rng(nf)
+    have = {(int(i), int(j)) for i, j in pairs}
+    far = set()
+    while len(far) < n_far:
+        i = int(rng.integers(0, nf)); j = int(rng.integers(0, nf))
+        i, j = min(i, j), max(i, j)
+        if min(j - i, nf - (j - i)) > 25 and (i, j) not in have:
+            far.add((i, j))
+    far = sorted(far)
+    all_pairs = np.array(sorted(have | set(far)), dtype=np.int32)
+    index_of = {(int(i), int(j)): k for k, (i, j) in enumerate(all_pairs)}
+    all_blocks = np.zeros((len(all_pairs), 6, 6))
+    for k, (i, j) in enumerate(pairs):
+        all_blocks[index_of[(int(i), int(j))]] = blocks[k]
+    S = A.copy()
+    for (i, j) in far:
+        b = rng.uniform(-0.3, 0.3, size=(6, 6))
+        all_blocks[index_of[(i, j)]] = b
+        S[6 * i:6 * i + 6, 6 * j:6 * j + 6] = b
+        S[6 * j:6 * j + 6, 6 * i:6 * i + 6] = b.T
+    assert _capi.bcr_plan(nf, all_pairs) is None                    # no exact schedule
+    plan = _capi.bcr_plan(nf, all_pairs, allow_rest=True)
+    assert plan is not None and plan["cyclic"] == bool(ring)
+    used = set((plan["src"][plan["src"] >= 0] & MASK).tolist())
+    left_out = [p for p in far if index_of[p] not in used]          # (a far pair may still fall into neighbouring blocks)
+    assert plan["n_rest"] == len(left_out) >= 0.9 * len(far)
+    assert used | {index_of[p] for p in left_out} == set(range(len(all_pairs)))      # every other block is in the tables
+    M = S.copy()                                                    # the in-band matrix: S without the blocks left out
+    for (i, j) in left_out:
+        M[6 * i:6 * i + 6, 6 * j:6 * j + 6] = 0.0
+        M[6 * j:6 * j + 6, 6 * i:6 * i + 6] = 0.0
+    keep = {}
+    x = _execute(plan, all_blocks, g, keep)
+    np.testing.assert_allclose(x, np.linalg.solve(M, -g), rtol=0, atol=1e-12)        # the plan factors M, exactly
+    r = rng.uniform(-1.0, 1.0, size=6 * nf)
+    np.testing.assert_allclose(_apply(plan, keep, r), np.linalg.solve(M, r), rtol=0, atol=1e-12)
+
+    def pcg(apply_m):
+        xk = np.zeros(6 * nf); rk = -g.copy(); zk = apply_m(rk); pk = zk.copy(); rz = rk @ zk
+        for it in range(1, 500):
+            q = S @ pk
+            alpha = rz / (pk @ q)
+            xk += alpha * pk; rk -= alpha * q
+            if np.linalg.norm(rk) <= 1e-10 * np.linalg.norm(g):
+                return xk, it
+            zk = apply_m(rk); rz_new = rk @ zk
+            pk = zk + (rz_new / rz) * pk; rz = rz_new
+        return xk, 500
+    x_pre, it_pre = pcg(lambda v: _apply(plan, keep, v))
+    np.testing.assert_allclose(x_pre, np.linalg.solve(S, -g), rtol=0, atol=1e-9)
+    assert it_pre <= 12, it_pre
+
+
+def test_too_much_remainder_is_no_plan():
+    nf = 200
+    rng = np.random.default_rng(3)
+    pairs = {(i, i) for i in range(nf)} | {(i, i + 1) for i in range(nf - 1)}
+    while len(pairs) < nf + 3 * (nf - 1):                             # twice as many far pairs as chain pairs
+        i, j = sorted(int(v) for v in rng.integers(0, nf, size=2))
+        if j - i > 30:
+            pairs.add((i, j))
+    assert _capi.bcr_plan(nf, np.array(sorted(pairs), dtype=np.int32), allow_rest=True) is None
