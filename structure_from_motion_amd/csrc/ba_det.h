@@ -33,7 +33,8 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build_det(const BuildArgs A, cons
     __shared__ unsigned char sLp[CHUNK_OBS];
     __shared__ unsigned char sLc[CHUNK_OBS];                             // local camera of each observation; 255 = fixed camera
     __shared__ int sPg[CHUNK_OBS / 2 + 2];
-    static_assert(CHUNK_OBS * DET_CS <= CHUNK_OBS * 18 && CHUNK_CAMS_WIDE < 255, "staging fits the T buffer");
+    __shared__ unsigned long long sMask[CHUNK_CAMS_WIDE * 4];            // per (local camera, wave): the lanes that observe it
+    static_assert(CHUNK_OBS * DET_CS <= CHUNK_OBS * 18 && CHUNK_CAMS_WIDE < 255 && CHUNK_OBS == 256, "staging fits the T buffer");
 
     const int ck = blockIdx.x, tid = threadIdx.x;
     const int ob = A.ck_obs[ck], nobs = A.ck_obs[ck + 1] - ob;
@@ -99,6 +100,12 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build_det(const BuildArgs A, cons
         }
     }
     if (tid == 0) sStart[npts] = nobs;
+    // which lanes of this wave observe local camera l (lane order = observation order: the gathers below walk the set
+    // bits from the lowest up, wave 0 first -- a fixed order)
+    for (int l = 0; l < ncam; ++l) {
+        const unsigned long long m = __ballot(act && lc == l);
+        if ((tid & 63) == 0) sMask[l * 4 + (tid >> 6)] = m;
+    }
     lds_barrier();
 
     // ---- phase 1b: one point per lane: V, g_p = the sum over its observations in lane order; damp, factor ---------
@@ -158,24 +165,36 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build_det(const BuildArgs A, cons
         for (int k = 0; k < 16; ++k) c[k] = cs[k];
     }
     lds_barrier();
-    for (int item = tid; item < ncam * 6; item += CHUNK_OBS) {
-        const int l = item / 6, row = item - l * 6;
+    // item = (local camera, row of U, wave whose lanes it walks): four neighbouring lanes per (camera, row), their
+    // partial sums joined by two DPP steps -- ((w0 + w1) + (w2 + w3)), the same order every time
+    for (int base = 0; base < ncam * 24; base += CHUNK_OBS) {
+        const int item = base + tid;
+        const bool on = item < ncam * 24;
+        const int l = on ? item / 24 : 0, rem = item - l * 24, row = on ? rem >> 2 : 0, w = rem & 3;
         double acc[6], g = 0.0;
 #pragma unroll
         for (int j = 0; j < 6; ++j) acc[j] = 0.0;
-        for (int o = 0; o < nobs; ++o) {
-            if ((int)sLc[o] != l) continue;
+        unsigned long long m = on ? sMask[l * 4 + w] : 0ull;
+        while (m) {
+            const int o = w * 64 + __builtin_ctzll(m);
+            m &= m - 1;
             const double *c = &sT[o * DET_CS];
             const double a0 = c[12] * c[row], a1 = c[13] * c[6 + row];
 #pragma unroll
             for (int j = 0; j < 6; ++j) acc[j] += a0 * c[j] + a1 * c[6 + j];
             g += c[row] * c[14] + c[6 + row] * c[15];
         }
-        double *out = &D.cam_slab[(size_t)(cb + l) * 33];
 #pragma unroll
-        for (int j = 0; j < 6; ++j)
-            if (j >= row) out[ut6(row, j)] = acc[j];
-        out[21 + row] = g;
+        for (int j = 0; j < 6; ++j) { acc[j] += dpp_f64<0xB1>(acc[j]); acc[j] += dpp_f64<0x4E>(acc[j]); }
+        g += dpp_f64<0xB1>(g);
+        g += dpp_f64<0x4E>(g);
+        if (on && w == 0) {
+            double *out = &D.cam_slab[(size_t)(cb + l) * 33];
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                if (j >= row) out[ut6(row, j)] = acc[j];
+            out[21 + row] = g;
+        }
     }
     lds_barrier();   // every lane is done with the camera staging
 
@@ -194,12 +213,17 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build_det(const BuildArgs A, cons
     }
     lds_barrier();
     // reduced gradient: -sum T_i u_p = -[Y x w; w], w = T' u, per local camera over its observations in lane order
-    if (tid < ncam) {
+    for (int base = 0; base < ncam * 4; base += CHUNK_OBS) {
+        const int item = base + tid;
+        const bool on = item < ncam * 4;
+        const int l = on ? item >> 2 : 0, w = item & 3;
         double g[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) g[k] = 0.0;
-        for (int o = 0; o < nobs; ++o) {
-            if ((int)sLc[o] != tid) continue;
+        unsigned long long m = on ? sMask[l * 4 + w] : 0ull;
+        while (m) {
+            const int o = w * 64 + __builtin_ctzll(m);
+            m &= m - 1;
             const double *t = &sT[o * T_STRIDE], *u = &sP[(int)sLp[o] * 9 + 6];
             const double w0 = t[0] * u[0] + t[1] * u[1] + t[2] * u[2], w1 = t[3] * u[0] + t[4] * u[1] + t[5] * u[2],
                          w2 = t[6] * u[0] + t[7] * u[1] + t[8] * u[2];
@@ -209,9 +233,13 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build_det(const BuildArgs A, cons
             g[2] += -(y0 * w1 - y1 * w0);
             g[3] += -w0; g[4] += -w1; g[5] += -w2;
         }
-        double *out = &D.cam_slab[(size_t)(cb + tid) * 33 + 27];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) out[k] = g[k];
+        for (int k = 0; k < 6; ++k) { g[k] += dpp_f64<0xB1>(g[k]); g[k] += dpp_f64<0x4E>(g[k]); }
+        if (on && w == 0) {
+            double *out = &D.cam_slab[(size_t)(cb + l) * 33 + 27];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) out[k] = g[k];
+        }
     }
 
     // ---- phase 3: Schur-complement blocks (k_build's phase 3 without the reduced-gradient part) -----------------------
@@ -315,10 +343,17 @@ __global__ __launch_bounds__(256) void k_det_reduce(int nf, int n_upper, const i
     if (t < nS) {
         const int slot = (int)(t / 36), k = (int)(t - (long long)slot * 36), kt = (k % 6) * 6 + k / 6;
         double v = 0.0;
-        const int e1 = s_ptr[slot + 1];
-        for (int e = s_ptr[slot]; e < e1; ++e) {
-            const unsigned r = s_idx[e];
-            v += blk_slab[(size_t)(r & 0x7fffffffu) * 36 + ((r >> 31) ? kt : k)];
+        const int e0 = s_ptr[slot], e1 = s_ptr[slot + 1];
+        for (int e = e0; e < e1; e += 4) {   // four rows per trip, their loads issued together; added in table order
+            unsigned r[4];
+            double x[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r[q] = s_idx[e + q < e1 ? e + q : e0];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x[q] = blk_slab[(size_t)(r[q] & 0x7fffffffu) * 36 + ((r[q] >> 31) ? kt : k)];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (e + q < e1) v += x[q];
         }
         S[t] = v;
         return;
@@ -327,8 +362,18 @@ __global__ __launch_bounds__(256) void k_det_reduce(int nf, int n_upper, const i
     if (t2 >= (long long)nf * 33) return;
     const int f = (int)(t2 / 33), k = (int)(t2 - (long long)f * 33);
     double v = 0.0;
-    const int e1 = c_ptr[f + 1];
-    for (int e = c_ptr[f]; e < e1; ++e) v += cam_slab[(size_t)c_idx[e] * 33 + k];
+    const int e0 = c_ptr[f], e1 = c_ptr[f + 1];
+    for (int e = e0; e < e1; e += 4) {
+        int r[4];
+        double x[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r[q] = c_idx[e + q < e1 ? e + q : e0];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x[q] = cam_slab[(size_t)r[q] * 33 + k];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (e + q < e1) v += x[q];
+    }
     if (k < 21) U[(size_t)f * 21 + k] = v;
     else if (k < 27) gc[(size_t)f * 6 + (k - 21)] = v;
     else gred[(size_t)f * 6 + (k - 27)] = v;
