@@ -171,6 +171,11 @@ int ba_eval_reprojection_errors_rt(const BaProblem *prob, const double *cam_rt, 
  *     calls that overlap on one GPU -- different streams or threads -- race on it.  Calls in stream order are fine. */
 int ba_eval_cost_noalloc(const BaProblem *prob, int32_t loss, double f_scale, double *out_cost_dev, void *stream);
 
+/* Optional: one tiny solve, so that the costs a fresh process pays once -- HIP runtime, code objects, the page-locked
+ * staging buffer: some 50 ms -- do not land on the caller's first BA call (the reference's driver calls inter_ba after
+ * its second registered image, Reconstruction.py:253-255).  BA_ERR_HIP without a device.  (No reference counterpart.) */
+int ba_warm_up(void);
+
 /* Host-only structure analysis (runs without a GPU). */
 int ba_analyze(const BaProblem *prob, BaAnalysis *out);
 

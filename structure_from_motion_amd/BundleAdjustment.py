@@ -19,7 +19,12 @@ import operator
 import numpy as np
 
 from . import _capi
-from .geometry import matrix_to_rvec, rvec_to_matrix
+from .geometry import matrices_to_rvecs, matrix_to_rvec, rvec_to_matrix
+
+try:   # the container walks of the marshalling in C (csrc/ba_pyhelp.c); without it the NumPy / itertools paths below
+    from . import _ba_pyhelp as _help
+except ImportError:   # pragma: no cover  (built by csrc/build.sh next to libba_hip.so)
+    _help = None
 
 __all__ = [
     "global_bundle_adjustment", "prepare_observations_from_image_data", "prepare_cameras_from_image_data",
@@ -28,6 +33,13 @@ __all__ = [
 
 # Last engine summary (status, iterations, costs, timings) -- extra, not part of the reference API.
 last_summary = None
+
+# The process's one-time GPU costs (runtime, code objects, staging buffer: some 50 ms) are paid at import, where the
+# reference pays for `import cv2` and scipy, not inside the driver's first inter_ba call.  BA_NO_WARM_UP=1 skips it; without
+# the library or a GPU it does nothing (the calls themselves report that, as the reference reports any failure).
+import os as _os
+if not _os.environ.get("BA_NO_WARM_UP"):
+    _capi.warm_up()
 
 
 def _anchor_ids(cam_ids, visited_ids):
@@ -163,6 +175,11 @@ def _valid_track_entries(cam_data, n_points):
 def _track_arrays(cam_data, n_points):
     """(keypoint indices, point indices) of one image as arrays, under the reference's rules (:260-264)."""
     ref_array, kp = cam_data[3], cam_data[5]
+    if _help is not None:
+        raw = _help.track_entries(ref_array, len(kp), n_points)
+        if raw is not None:
+            a = np.frombuffer(raw, dtype=np.int64).reshape(-1, 2)
+            return a[:, 0], a[:, 1]
     if isinstance(ref_array, list) and set(map(type, ref_array)) <= {int}:
         ref = np.asarray(ref_array, dtype=np.int64)
         ok = (ref != -1) & (ref >= 0) & (ref < n_points)
@@ -182,6 +199,10 @@ _PT = operator.attrgetter("pt")
 def _keypoint_xy(kp, kidx):
     """(len(kidx), 2) float64 pixel coordinates ``kp[k].pt`` (:269).  One flat iterator into ``np.fromiter``: less than
     half the time of ``np.array`` over a list of tuples, and the keypoints are most of what a ``final_ba`` call reads."""
+    if _help is not None:
+        out = np.empty((len(kidx), 2), dtype=np.float64)
+        if _help.keypoints_xy(kp, np.ascontiguousarray(kidx, dtype=np.int64), out):
+            return out
     flat = itertools.chain.from_iterable(map(_PT, map(kp.__getitem__, kidx.tolist())))
     return np.fromiter(flat, dtype=np.float64, count=2 * len(kidx)).reshape(-1, 2)
 
@@ -189,6 +210,10 @@ def _keypoint_xy(kp, kidx):
 def _rows_to_array(rows):
     """``np.asarray(rows, float64)`` for the driver's list of equally long point rows ([x, y, z, r, g, b] lists,
     ``Reconstruction.py:41-47``), through a flat iterator (about half the time); anything else goes to ``np.asarray``."""
+    if _help is not None and isinstance(rows, list) and rows and isinstance(rows[0], (list, tuple)) and len(rows[0]) > 0:
+        out = np.empty((len(rows), len(rows[0])), dtype=np.float64)
+        if _help.rows_to_array(rows, out) is not None:
+            return out
     if isinstance(rows, list) and rows and isinstance(rows[0], (list, tuple)):
         w = len(rows[0])
         if w and set(map(len, rows)) == {w}:
@@ -215,12 +240,14 @@ def _image_data_to_arrays(image_data, all_points_3D, visited_ids, keypoints=None
     index_of = {cid: i for i, cid in enumerate(cam_ids)}
     n_c = len(cam_ids)
     cam_pose, cam_intr = np.empty((n_c, 6)), np.empty((n_c, 4))
+    Rs = np.empty((n_c, 3, 3))
     for i, cid in enumerate(cam_ids):
         R, t, K = image_data[cid][0], image_data[cid][1], image_data[cid][2]
-        cam_pose[i, :3] = matrix_to_rvec(np.asarray(R, dtype=np.float64))
+        Rs[i] = np.asarray(R, dtype=np.float64).reshape(3, 3)
         cam_pose[i, 3:] = np.asarray(t, dtype=np.float64).reshape(3)
         K = np.asarray(K, dtype=np.float64)
         cam_intr[i] = (K[0, 0], K[1, 1], K[0, 2], K[1, 2])
+    cam_pose[:, :3] = matrices_to_rvecs(Rs)       # (one batched SVD; matrix_to_rvec per camera otherwise)
     oc, op, oxy = [], [], []
     for img_id in usable:                         # per occurrence, like the reference's loop (:253)
         cam_data = image_data[img_id]
@@ -285,7 +312,13 @@ def _ba_from_image_data(image_data, all_points_3D, visited_ids, loss_f_scale, ma
             else:
                 entry[0], entry[1] = R_new[i].copy(), arr.cam_pose[i, 3:].reshape(3, 1).copy()
             image_data[cid] = tuple(entry)
-        if colours is not None:
+        new_points = None
+        if _help is not None:
+            # (x, y, z from the solve, the colour entries are the caller's own objects -- as the reference's `+ colours`, :96-97)
+            new_points = _help.rows_with_xyz(all_points_3D, np.ascontiguousarray(arr.points))
+        if new_points is not None:
+            pass
+        elif colours is not None:
             new_points = np.concatenate([arr.points, colours], axis=1).tolist()
         else:
             new_points = [[x, y, z] + list(p[3:6]) for (x, y, z), p in zip(arr.points.tolist(), all_points_3D)]

@@ -26,7 +26,7 @@ EXPORTED = [
     "ba_get_state", "ba_get_cost", "ba_get_reduced_system", "ba_get_reduced_blocks", "ba_synchronize",
     "ba_set_values", "ba_set_collective_mode", "ba_get_stream", "ba_eval_cost_noalloc",
     "ba_eval_reprojection_errors_rt", "ba_get_reprojection_errors", "ba_rccl_unique_id", "ba_rccl_init", "ba_append",
-    "ba_bcr_plan", "ba_bcr_plan_rest",
+    "ba_bcr_plan", "ba_bcr_plan_rest", "ba_warm_up",
 ]
 
 
@@ -129,6 +129,15 @@ def load():
             getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
+
+
+def warm_up():
+    """One tiny solve (``ba_warm_up``): pays the per-process one-time costs now instead of on the first BA call.
+    Returns False -- never raises -- when the library or a GPU is missing."""
+    try:
+        return load().ba_warm_up() == BA_OK
+    except Exception:
+        return False
 
 
 def check(code):

@@ -401,8 +401,11 @@ inline bool bcr_plan_with_order(int nf, const int64_t *keys, size_t nk, const st
 // them), else along the chain coordinate of bcr_chain_order, else in reverse Cuthill-McKee order.  false: no order tried makes the pattern a chain / ring with a half
 // bandwidth of at most 21 cameras (or it is too small to bother).
 // allow_rest: when no order makes the WHOLE pattern a chain / ring, accept a plan for its in-band part (cameras in
-// index order, else along the chain coordinate) if that part holds at least half of the off-diagonal blocks -- the
-// factorisation of the in-band part then preconditions a CG iteration on the whole system (P.n_rest > 0).
+// index order, else along the chain coordinate) if that part holds at least an eighth of the off-diagonal blocks -- the
+// factorisation of the in-band part then preconditions a CG iteration on the whole system (P.n_rest > 0).  (A revisited
+// landmark couples every camera of its first window with every camera of the second: far-apart blocks are many, each
+// carried by a point or two, while an in-band block is carried by dozens.  Whether the preconditioner is any good shows
+// at run time -- do_bcr_pcg gives it up when CG does not converge quickly.)
 inline bool bcr_make_plan(int nf, const int64_t *keys, size_t nk, BcrPlan &P, bool allow_rest = false) {
     if (nf < 2) { P = BcrPlan{}; return false; }
     std::vector<int32_t> order(nf), chain;
@@ -421,8 +424,8 @@ inline bool bcr_make_plan(int nf, const int64_t *keys, size_t nk, BcrPlan &P, bo
     }
     if (!allow_rest || nf < 2 * BCR_MAX_BAND) return false;
     const int64_t n_off = (int64_t)nk - nf;   // (every diagonal block is in the pattern)
-    if (bcr_plan_with_order(nf, keys, nk, order, P, true) && 2 * P.n_rest <= n_off) return true;
-    if (have_chain && bcr_plan_with_order(nf, keys, nk, chain, P, true) && 2 * P.n_rest <= n_off) {
+    if (bcr_plan_with_order(nf, keys, nk, order, P, true) && P.n_rest <= 7 * (n_off - P.n_rest)) return true;
+    if (have_chain && bcr_plan_with_order(nf, keys, nk, chain, P, true) && P.n_rest <= 7 * (n_off - P.n_rest)) {
         P.reordered = true;
         return true;
     }

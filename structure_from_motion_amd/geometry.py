@@ -38,12 +38,7 @@ def rvec_to_matrix(rvec):
     return np.where(small[..., None, None], eye, R)
 
 
-def matrix_to_rvec(Rin):
-    """Rotation matrix (3,3) -> axis-angle (3,) (``cv2.Rodrigues`` matrix->vector):
-    nearest rotation by SVD, then the antisymmetric part scaled by theta/(2 sin theta),
-    with the separate branch near theta = pi."""
-    Rin = np.asarray(Rin, dtype=np.float64).reshape(3, 3)
-    U, _, Vt = np.linalg.svd(Rin)
+def _rvec_from_svd(U, Vt):
     R = U @ Vt
     r = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
     s = np.sqrt(float(r @ r) * 0.25)
@@ -59,6 +54,28 @@ def matrix_to_rvec(Rin):
         v = np.array([rx, ry, rz])
         return v * (theta / np.linalg.norm(v))
     return r * (theta / (2.0 * s))
+
+
+def matrix_to_rvec(Rin):
+    """Rotation matrix (3,3) -> axis-angle (3,) (``cv2.Rodrigues`` matrix->vector):
+    nearest rotation by SVD, then the antisymmetric part scaled by theta/(2 sin theta),
+    with the separate branch near theta = pi."""
+    Rin = np.asarray(Rin, dtype=np.float64).reshape(3, 3)
+    U, _, Vt = np.linalg.svd(Rin)
+    return _rvec_from_svd(U, Vt)
+
+
+def matrices_to_rvecs(Rs):
+    """:func:`matrix_to_rvec` for a stack (n, 3, 3) -> (n, 3) with ONE stacked SVD call (most of the time of the scalar
+    function is the call into LAPACK, not its arithmetic); everything behind the SVD is the scalar code, per matrix,
+    so the two agree bit for bit."""
+    Rs = np.asarray(Rs, dtype=np.float64).reshape(-1, 3, 3)
+    out = np.zeros((len(Rs), 3))
+    if len(Rs):
+        U, _, Vt = np.linalg.svd(Rs)
+        for i in range(len(Rs)):
+            out[i] = _rvec_from_svd(U[i], Vt[i])
+    return out
 
 
 def project_points(cam_pose, cam_intr, points, obs_cam, obs_pt):
