@@ -203,7 +203,8 @@ BaHandle *ba_create(const BaProblem *prob, const BaOptions *opt);
 void ba_destroy(BaHandle *h);
 /* Extra co-visibility pairs (free-camera index pairs i<=j, 2*n_pairs int32) to add to the
  * reduced-camera-system pattern: ranks of a sharded solve must share ONE pattern.  Must be
- * called before the first build. ba_get_pattern returns this rank's own pairs. */
+ * called before the first build, and again after a ba_append on a sharded handle. ba_get_pattern returns this rank's own
+ * pairs together with the extra ones it was given before. */
 int ba_get_pattern(BaHandle *h, int32_t *out_pairs, int64_t capacity, int64_t *n_pairs);
 int ba_set_pattern(BaHandle *h, const int32_t *pairs, int64_t n_pairs);
 int ba_set_collective(BaHandle *h, BaCollectiveFn fn, void *user, int32_t rank, int32_t world);
@@ -245,7 +246,11 @@ int ba_set_values(BaHandle *h, const BaProblem *prob, const BaOptions *opt);
  *              re-allocated geometrically), old block slots keep their numbers.
  *   *mode = 0  rebuilt inside the handle: an old track grew, a long-track ("heavy") point is involved, or the prefix
  *              rule does not hold (e.g. the gauge changed at 15 images, BundleAdjustment.py:38).  Same result, full analysis.
- * Not for sharded handles (BA_ERR_UNSUPPORTED); a shrunken problem is BA_ERR_INVALID.  mode may be NULL.
+ * A shrunken problem is BA_ERR_INVALID.  mode may be NULL.
+ * On a sharded handle (ba_set_collective / ba_rccl_init) every rank appends its own shard's growth -- the cameras are
+ * replicated, so every rank passes the same grown camera arrays -- and the ranks then agree on ONE pattern again:
+ * ba_get_pattern, union over the ranks, ba_set_pattern (collectively, as at set-up); until then ba_build / ba_run on the
+ * handle return BA_ERR_INVALID.
  * If the call fails after the structure has begun to change (out of memory, a HIP error), the handle is marked
  * unusable: every other entry point returns BA_ERR_INVALID for it until a later ba_append succeeds (it then rebuilds
  * the whole structure) or the handle is destroyed. */

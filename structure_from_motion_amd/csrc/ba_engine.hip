@@ -350,7 +350,8 @@ struct BaHandle {
     int dense_fallbacks = 0;
     // AUTO between the blocked dense Cholesky and block-Jacobi PCG on a (nearly) full pattern: both are timed once, then
     // the faster one is kept (do_step)
-    int auto_phase = 0;            // 0: time the direct solver next, 1: time PCG next, 2: decided
+    int auto_phase = -1;           // -1: first use of the direct solver (allocations, attributes: not timed), 0: time the
+                                   // direct solver next, 1: time PCG next, 2: decided
     bool auto_use_pcg = false;
     float auto_ms_direct = 0.f, auto_ms_pcg = 0.f;
     int auto_pcg_iters = 0;
@@ -372,6 +373,7 @@ struct BaHandle {
     double initial_cost = NAN;
     bool built = false;
     bool poisoned = false;   // a ba_append failed half way: the host structure and the device arrays may disagree
+    bool pattern_stale = false;   // sharded handle after ba_append: the ranks must agree on a new pattern (ba_set_pattern) first
     double t_setup_ms = 0.0;
 
     ~BaHandle() {
@@ -497,6 +499,8 @@ HeavyArgs heavy_args(BaHandle *h) {
 
 // (x, lambda on device) -> cost, S, g_red, block-Jacobi inverse.  Timed pieces: ev0..ev1 fused kernel.
 int do_build(BaHandle *h, bool timed) {
+    if (h->pattern_stale)
+        return fail(BA_ERR_INVALID, "sharded handle after ba_append: call ba_set_pattern with the union of the ranks' patterns first");
     if (!h->pattern_uploaded) {
         int e = upload_pattern(h);
         if (e) return e;
@@ -885,7 +889,10 @@ int do_step(BaHandle *h) {
     const bool auto_pick = ls == BA_SOLVER_AUTO && !can_dense && !can_bcr && !can_band && can_big && dense_pattern;
     bool time_direct = false, time_pcg = false, skip_direct = false;
     if (auto_pick) {
-        if (h->auto_phase == 0) time_direct = true;
+        if (h->auto_phase < 0) {   // (the direct solver's first use allocates its work space: not a timing)
+            time_direct = h->dense_a.n == big_matrix_doubles(n_red);
+            h->auto_phase = 0;
+        } else if (h->auto_phase == 0) time_direct = true;
         else if (h->auto_phase == 1) { time_pcg = true; skip_direct = true; }
         else skip_direct = h->auto_use_pcg;
     }
@@ -991,7 +998,7 @@ int upload_values(BaHandle *h, const HostProblem &hp) {
     h->cur = 0;
     h->total_pcg = 0;
     h->dense_fallbacks = 0;
-    h->auto_phase = 0;
+    h->auto_phase = -1;
     h->initial_cost = NAN;
     h->built = false;
     HIPCHK(hipMemcpyAsync(h->state.p, &h->hstate, sizeof(LmState), hipMemcpyHostToDevice, st));
@@ -1037,6 +1044,8 @@ int alloc_work(BaHandle *h) {
     HIPCHK(h->pq.alloc_grow((size_t)nf * 6));
     HIPCHK(h->pqv.alloc_grow((size_t)nf * 6));
     HIPCHK(h->pcg_sc.alloc(1));
+    HIPCHK(h->pcg_part.alloc_grow((size_t)7 * ((nf + 255) / 256) + (size_t)2 * ((nf + 3) / 4) + 1));
+    if (!h->hpcg_pinned) HIPCHK(hipHostMalloc((void **)&h->hpcg_pinned, sizeof(PcgScalars), hipHostMallocDefault));
     HIPCHK(h->state.alloc(1));
     // solver work space is sized on first use: drop what belonged to another structure
     h->dense_a.release(); h->dense_linv.release();
@@ -1380,7 +1389,6 @@ int ba_append(BaHandle *h, const BaProblem *grown, const BaOptions *opt, int32_t
     if (!h->poisoned && (grown->n_cams < s.n_cams || grown->n_points < s.n_points || grown->n_obs < s.n_obs))
         return fail(BA_ERR_INVALID, "ba_append: the problem shrank (%d cameras, %d points, %lld observations against the handle's %d, %d, %lld)",
                     grown->n_cams, grown->n_points, (long long)grown->n_obs, s.n_cams, s.n_points, (long long)s.n_obs);
-    if (h->coll) return fail(BA_ERR_UNSUPPORTED, "ba_append on a sharded handle (the ranks would have to agree on a new pattern)");
     BaOptions o = h->opt;
     if (opt) {
         o = *opt;
@@ -1415,6 +1423,8 @@ int ba_append(BaHandle *h, const BaProblem *grown, const BaOptions *opt, int32_t
         h->opt = o;
         if ((e = upload_values(h, hp))) return e;
         h->poisoned = false;
+        // (a sharded handle: this rank's own pattern has changed, and so may the others' -- the union has to be made again)
+        h->pattern_stale = h->coll != nullptr;
         if (mode) *mode = appended ? 1 : 0;
         h->t_setup_ms = now_ms() - t0;
         return BA_OK;
@@ -1504,6 +1514,7 @@ int ba_set_pattern(BaHandle *h, const int32_t *pairs, int64_t n_pairs) {
         finalize_pattern(h->sym, extra);
         (void)hipSetDevice(h->device);
         h->built = false;
+        h->pattern_stale = false;
         return upload_pattern(h);
     } catch (const std::bad_alloc &) {
         return fail(BA_ERR_NOMEM, "out of host memory");

@@ -124,3 +124,20 @@ def create_sharded_handle(shard, rank, world, group=None, stream_ordered=True, f
             coll = make_collective(group, h.stream() if stream_ordered else None)
             h.set_collective(coll, rank, world, stream_ordered=coll.stream_ordered)
     return h
+
+
+def append_sharded(h, grown_shard, world, group=None, **opts):
+    """``ba_append`` on a sharded handle (the incremental driver's growth, ``Reconstruction.py:244-255``, on more than one
+    GPU): every rank appends the growth of ITS shard -- new points and their observations at the end of its arrays; the
+    cameras are replicated, so every rank passes the same grown camera arrays -- and the ranks then agree on one block
+    pattern again (collective: every rank must call this).  Returns True when this rank's structure was extended in
+    place."""
+    import torch.distributed as dist
+    appended = h.append(_capi.Arrays.from_dict(grown_shard), **opts)
+
+    def gather(obj):
+        out = [None] * world
+        dist.all_gather_object(out, obj, group=group)
+        return out
+    h.set_pattern(union_pattern(h.pattern(), gather))
+    return appended

@@ -153,3 +153,39 @@ def engine_sharded_empty_rank(rank, world, port, out_dir):
              iters=s["iterations"], cost0=s["initial_cost"])
     h.close()
     dist.destroy_process_group()
+
+
+def engine_sharded_append(rank, world, port, out_dir):
+    """GPU, two ranks on one device: the sharded handles solve a problem with its first cameras and points, then the
+    problem GROWS (the remaining cameras, the points only they see, appended at the end of every rank's shard) --
+    ba_append on each rank, the pattern union again, and the next solve."""
+    import torch
+    dist = _init(rank, world, port)
+    torch.cuda.set_device(0)
+    from structure_from_motion_amd import dist as badist
+    from test_gpu_dist import growing_problem
+    first, full = growing_problem()
+    sh1, _ = badist.shard_points(first, rank, world)
+    h = badist.create_sharded_handle(sh1, rank, world, loss="huber", f_scale=1.5, max_iter=40, device=0)
+    s1 = h.run()
+    # this rank's grown shard: its old points first (same order), then its share of the new points
+    n1 = len(first["points"])
+    new_pts = np.arange(n1, len(full["points"]))
+    mine_new = new_pts[rank::world]
+    old_idx = badist.shard_points(first, rank, world)[1]
+    keep = np.concatenate([old_idx, mine_new])
+    remap = -np.ones(len(full["points"]), dtype=np.int64)
+    remap[keep] = np.arange(len(keep))
+    m_old = np.isin(full["obs_pt"][:len(first["obs_cam"])], old_idx)
+    sel_old = np.flatnonzero(m_old)
+    sel_new = len(first["obs_cam"]) + np.flatnonzero(np.isin(full["obs_pt"][len(first["obs_cam"]):], mine_new))
+    sel = np.concatenate([sel_old, sel_new])
+    grown = dict(cam_pose=full["cam_pose"], cam_intr=full["cam_intr"], cam_fixed=full["cam_fixed"], points=full["points"][keep],
+                 obs_cam=full["obs_cam"][sel], obs_pt=remap[full["obs_pt"][sel]].astype(np.int32), obs_xy=full["obs_xy"][sel])
+    appended = badist.append_sharded(h, grown, world, loss="huber", f_scale=1.5, max_iter=40, device=0)
+    s2 = h.run()
+    cp, pts = h.state()
+    np.savez(os.path.join(out_dir, f"app{rank}.npz"), cp=cp, pts=pts, keep=keep, cost1=s1["final_cost"], cost2=s2["final_cost"],
+             status2=s2["status"], iters2=s2["iterations"], appended=int(appended), cost2_0=s2["initial_cost"])
+    h.close()
+    dist.destroy_process_group()

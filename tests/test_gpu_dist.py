@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 import torch.multiprocessing as mp
-from dist_workers import engine_nccl_single_rank, engine_sharded_empty_rank, engine_sharded_solve
+from dist_workers import engine_nccl_single_rank, engine_sharded_append, engine_sharded_empty_rank, engine_sharded_solve
 from test_dist_cpu import _free_port
 
 from structure_from_motion_amd import _capi, synthetic
@@ -128,3 +128,48 @@ def test_deterministic_mode_across_ranks(gpu, tmp_path, monkeypatch):
     assert float(a0["cost"]) == float(b0["cost"]) == float(a1["cost"])
     assert int(a0["iters"]) == s["iterations"] and int(a0["pcg"]) == 0
     assert abs(float(a0["cost"]) - s["final_cost"]) <= 1e-13 * s["final_cost"]
+
+
+def growing_problem():
+    """(first, full): a ring problem with 14 of its 16 cameras and the points they see, and the whole of it -- the last
+    two cameras and the points only they see arrive later, at the END of the camera / point / observation arrays (what
+    the reference's driver appends per registered image, Reconstruction.py:244-251)."""
+    p = synthetic.make_ring(16, 900, seed=41, visibility="sfm", n_seed_points=120, n_fixed=2, noise=0.3)
+    late = p["obs_cam"] >= 14
+    late_pts = np.unique(p["obs_pt"][late])
+    assert not np.isin(p["obs_pt"][~late], late_pts).any()          # the new images' points are their own
+    old_pts = np.setdiff1d(np.arange(len(p["points"])), late_pts)
+    order = np.concatenate([old_pts, late_pts])
+    remap = np.empty(len(order), dtype=np.int64)
+    remap[order] = np.arange(len(order))
+    oo = np.concatenate([np.flatnonzero(~late), np.flatnonzero(late)])
+    full = dict(cam_pose=p["cam_pose"], cam_intr=p["cam_intr"], cam_fixed=p["cam_fixed"], points=p["points"][order],
+                obs_cam=p["obs_cam"][oo], obs_pt=remap[p["obs_pt"][oo]].astype(np.int32), obs_xy=p["obs_xy"][oo])
+    n_o1, n_p1 = int((~late).sum()), len(old_pts)
+    first = dict(cam_pose=full["cam_pose"][:14], cam_intr=full["cam_intr"][:14], cam_fixed=full["cam_fixed"][:14],
+                 points=full["points"][:n_p1], obs_cam=full["obs_cam"][:n_o1], obs_pt=full["obs_pt"][:n_o1], obs_xy=full["obs_xy"][:n_o1])
+    return first, full
+
+
+def test_append_on_sharded_handles(gpu, tmp_path):
+    """f1 on more than one rank: ba_append on every rank's handle + the pattern union again = a fresh single handle on
+    the grown problem (same initial cost bit for bit apart from the summation order, same minimum)."""
+    mp.spawn(engine_sharded_append, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "app0.npz"), np.load(tmp_path / "app1.npz")
+    first, full = growing_problem()
+    a1 = _capi.Arrays.from_dict(first)
+    s1 = _capi.solve(a1, loss="huber", f_scale=1.5, max_iter=40)
+    assert abs(float(r0["cost1"]) - s1["final_cost"]) <= 1e-8 * s1["final_cost"]
+    # the grown problem from the state the sharded handles were given: old cameras / points as the caller holds them
+    # (the reference's driver passes its current image_data; here: the initial values again), new ones initial
+    a2 = _capi.Arrays.from_dict(full)
+    s2 = _capi.solve(a2, loss="huber", f_scale=1.5, max_iter=40)
+    for r in (r0, r1):
+        assert abs(float(r["cost2_0"]) - s2["initial_cost"]) <= 1e-12 * s2["initial_cost"]
+        assert int(r["status2"]) == s2["status"] and abs(float(r["cost2"]) - s2["final_cost"]) <= 1e-7 * s2["final_cost"]
+    np.testing.assert_array_equal(r0["cp"], r1["cp"])
+    assert np.allclose(r0["cp"], a2.cam_pose, atol=1e-5)
+    pts = np.empty_like(full["points"])
+    pts[r0["keep"]] = r0["pts"]
+    pts[r1["keep"]] = r1["pts"]
+    assert np.allclose(pts, a2.points, atol=1e-4)

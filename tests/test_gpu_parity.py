@@ -821,8 +821,10 @@ def test_city_shard_10k_cameras(gpu):
         # -- differ by 1.3e-11 relative; 1e-12 holds up to the 5 M observations of the Venice shape)
         assert abs(h.cost() - nb["F"]) <= 1e-10 * nb["F"]
         r = h.reduced_system(want_points=True, want_dense=False)
-        assert rel(r["U"][free], nb["U"][free]) < 1e-10 and rel(r["gc"][free], nb["gc"][free]) < 1e-10
-        assert rel(r["V"], nb["V"]) < 1e-10 and rel(r["gp"], nb["gp"]) < 1e-10
+        # (norm-wise, as for the Venice shape; among 12.5 M observations the few points closest to a camera carry most of
+        # the norm and of its rounding, 1 / z^2: measured 4.8e-10 on U)
+        assert rel(r["U"][free], nb["U"][free]) < 2e-9 and rel(r["gc"][free], nb["gc"][free]) < 2e-9
+        assert rel(r["V"], nb["V"]) < 2e-9 and rel(r["gp"], nb["gp"]) < 2e-9
         assert rel(r["gred"], gred) < 1e-8
         assert rel(h.schur_matvec(v), Sv) < 1e-8
         del nb, r
