@@ -78,6 +78,19 @@ def other_configs(_capi, synthetic):
     # module from the reference's containers (image_data tuples, point lists) = what Reconstruction.py:302-304 pays,
     # marshalling included; (3) the same through BASession (array marshalling, cached keypoints)
     p = synthetic.make_config("temple")
+    fx = os.path.join(ROOT, "tests", "golden", "temple_final.npz")
+    temple_source = "synthetic.make_config('temple')"
+    if os.path.exists(fx):
+        # the fixture problem: the 20 467 vertices of the reference's own Temple cloud (src/temple_new.ply), 47 ring cameras,
+        # at the reference's own x0 (tests/golden/make_golden.py --config-size)
+        g = dict(np.load(fx, allow_pickle=False))
+        free = g["cam_fixed"] == 0
+        nf = int(free.sum())
+        cam_pose = g["cam_pose"].copy()
+        cam_pose[free] = g["x0"][:6 * nf].reshape(nf, 6)
+        p = dict(cam_pose=cam_pose, cam_intr=g["cam_intr"], cam_fixed=g["cam_fixed"], points=g["x0"][6 * nf:].reshape(-1, 3).copy(),
+                 obs_cam=g["obs_cam"], obs_pt=g["obs_pt"], obs_xy=g["obs_xy"])
+        temple_source = "tests/golden/temple_final.npz (structure: the reference's temple_new.ply)"
     runs = []
     for _rep in range(3):          # (best of three, as for the host-API entries below; the first call of a process also pays
         arr = _capi.Arrays.from_dict(p)   # one-time costs: code objects, the page-locked staging buffer of the uploads)
@@ -86,6 +99,7 @@ def other_configs(_capi, synthetic):
         runs.append(((time.perf_counter() - t0) * 1e3, s))
     wall, s = min(runs, key=lambda r: r[0])
     out["temple_final_ba"] = {"cameras": len(p["cam_pose"]), "points": len(p["points"]), "observations": len(p["obs_cam"]),
+                              "problem": temple_source,
                               "status": s["status"], "lm_steps": s["iterations"], "cost": [s["initial_cost"], s["final_cost"]],
                               "solve_ms": s["t_solve_ms"], "setup_ms": s["t_setup_ms"],
                               "wall_ms_from_arrays": wall, "wall_ms_from_arrays_first_call": runs[0][0]}
@@ -137,6 +151,26 @@ def other_configs(_capi, synthetic):
                                        "cost_after": [s_app["final_cost"], s_new["final_cost"]]}
     except Exception as e:
         out["fountain_incremental"] = {"error": repr(e)}
+    # BaOptions.deterministic = 1 on the headline workload: the atomic-free build (owner-lane gathers, slab rows, fixed-order
+    # segmented sum) and a whole LM step in that mode, beside the default (atomic) mode's numbers of the headline line
+    try:
+        pv = synthetic.make_config("venice1778")
+        with _capi.Handle(_capi.Arrays.from_dict(pv), loss="huber", f_scale=1.0, max_iter=300, deterministic=1) as h:
+            h.build_bench(1e-4, warmup=0, reps=3)
+            ms_pass, ms_k = h.build_bench(1e-4, warmup=0, reps=20)
+            h.run(1)
+            h.synchronize()
+            t0 = time.perf_counter()
+            s = h.run(10)
+            h.synchronize()
+            dt = time.perf_counter() - t0
+        steps = max(s["iterations"] - 1, 1)
+        out["venice1778_deterministic"] = {"observations": len(pv["obs_cam"]), "build_ms": ms_pass, "k_build_det_ms": ms_k,
+                                           "observations_per_sec": len(pv["obs_cam"]) / (ms_pass * 1e-3),
+                                           "lm_iters_per_sec": steps / dt, "lm_pcg_iterations": s["pcg_iterations"]}
+        del pv
+    except Exception as e:
+        out["venice1778_deterministic"] = {"error": repr(e)}
     p = synthetic.make_config("ladybug1723")
     with _capi.Handle(_capi.Arrays.from_dict(p), loss="huber", f_scale=1.0, max_iter=300) as h:
         h.build_bench(1e-4, warmup=0, reps=3)
