@@ -387,6 +387,15 @@ class Handle:
     def synchronize(self):
         check(self._lib.ba_synchronize(self.h))
 
+    def debug_bcr_apply(self):
+        """Diagnostic: relative difference between the cyclic reduction's direct solve of S x = -g and its preconditioner
+        path (explicit inverses + sweeps) on the same right-hand side (``ba_debug_bcr_apply``, not part of the header)."""
+        rel = C.c_double()
+        self._lib.ba_debug_bcr_apply.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        self._lib.ba_debug_bcr_apply.restype = C.c_int
+        check(self._lib.ba_debug_bcr_apply(self.h, C.byref(rel)))
+        return rel.value
+
     def pattern(self):
         n = C.c_int64()
         check(self._lib.ba_get_pattern(self.h, None, 0, C.byref(n)))

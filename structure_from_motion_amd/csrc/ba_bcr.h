@@ -436,7 +436,8 @@ inline bool bcr_make_plan(int nf, const int64_t *keys, size_t nk, BcrPlan &P, bo
 // m diagonal blocks D_k, the coupling slots, and m more blocks for the factors L_k: D_k stays READ-ONLY while a level is
 // being factored -- both workgroups of an eliminated block load it, and nothing orders the second one's load before
 // the first one's write-back (they may not even be resident together), so the factor goes to a block of its own
-inline size_t bcr_matrix_doubles(const BcrPlan &P) { return (size_t)(2 * P.m + P.n_slots) * P.nb * P.nb; }
+// (and m more for the explicit inverses X_k = L_k^-1 of the preconditioner sweeps, k_bcr_inv)
+inline size_t bcr_matrix_doubles(const BcrPlan &P) { return (size_t)(3 * P.m + P.n_slots) * P.nb * P.nb; }
 inline size_t bcr_vec_doubles(const BcrPlan &P) { return (size_t)P.m * P.nb; }
 inline size_t bcr_linv_doubles(const BcrPlan &P) { return (size_t)P.m * P.nt * 256; }
 #ifndef BA_BCR_BACK_THREADS
@@ -829,84 +830,194 @@ __global__ __launch_bounds__(BA_BCR_BACK_THREADS) void k_bcr_back(const BcrElim 
     }
 }
 
-// ------------------------------------------------------------------------------------------------ forward (new right-hand side)
-// The factorisation as a PRECONDITIONER: z = M^-1 r for a new right-hand side r through the stored factors -- forward
-// here, then k_bcr_back as it is.  One workgroup per block eliminated at this level:
-//     b_k = r_k - sum over the updates the block has received (W[slot] y_j, the plan's pending list, schedule order),
-//     y_k = L_k^-1 b_k   (blocked substitution out of LDS: y_s = Linv_s b_s per 16-row tile, then the rows below lose it)
-// Every sum has a fixed order (one wave per row of W, DPP tree), so the preconditioner is a fixed linear operator:
-// bit-identical from run to run.  `done` (may be null): the PCG's convergence flag -- a launch queued behind a
-// converged iteration returns at once.
-inline size_t bcr_fwd_lds_bytes(int nt) {
-    const int nb = 16 * nt;
-    return ((size_t)nb * (nb + 1) + (size_t)nt * 256 + nb + 16) * sizeof(double);
-}
+// ------------------------------------------------------------------------------------------------ the factorisation as a preconditioner
+// z = M^-1 r for a NEW right-hand side through the stored factors (do_bcr_pcg: CG on the whole S, preconditioned by the
+// in-band part M).  A CG iteration is as fast as this sweep, and the sweep is 2 (levels) dependent launches, so each
+// launch must be short: with the explicit inverses X_k = L_k^-1 (k_bcr_inv, once per factorisation) every step of the
+// sweep is a dense matrix-vector product streamed from L2 -- no triangular substitution, no LDS staging of a factor:
+//     forward   y_k = X_k (r_k - sum over the updates the block has received, W[slot] y_j: the plan's pending list)
+//     backward  x_k = X_k^T (y_k - W_u^T x_u - W_v^T x_v)
+// Every sum has a fixed order (lanes over columns, DPP tree, then the waves' partials in wave order), so M^-1 is a fixed
+// linear operator: bit-identical from run to run.  `done` (may be null): the PCG's convergence flag -- a launch queued
+// behind a converged iteration returns at once.
+
+// X_k = L_k^-1, full lower-triangular block, for every block of the plan in ONE launch: wave j of a workgroup owns block
+// column j (16 columns) and walks down it tile by tile, X_jj = the diagonal tile's inverse (from the factorisation),
+// X_ij = -X_ii sum_{k = j .. i-1} L_ik X_kj -- the recurrence of k_big_potrf (ba_dense_big.h), operands L_ik straight from L2,
+// the column's finished tiles in LDS; block columns do not depend on each other: no workgroup barrier.
 template <int NT>
-__global__ __launch_bounds__(BA_BCR_BACK_THREADS) void k_bcr_fwd(const BcrElim *__restrict__ elims, const int32_t *__restrict__ pend_ptr,
-                                                 const int32_t *__restrict__ pend, const double *__restrict__ Lf,
+__global__ __launch_bounds__(64 * NT) void k_bcr_inv(const double *__restrict__ Lf, const double *__restrict__ Linv16, double *__restrict__ Xf) {
+    constexpr int NB = 16 * NT;
+    __shared__ double sX[NT * (NT + 1) / 2 * 272];   // tile (i, j), i >= j, of column j at (j NT - j (j - 1) / 2 + (i - j)) * 272, 16 x 17
+    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+    const int j = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const double *L = Lf + (size_t)k * NB * NB, *li = Linv16 + (size_t)k * NT * 256;
+    double *X = Xf + (size_t)k * NB * NB;
+    double *col = sX + (j * NT - j * (j - 1) / 2) * 272;
+    {
+        double *t = col;   // X_jj
+#pragma unroll
+        for (int v = 0; v < 4; ++v) t[(l4 + 4 * v) * 17 + l15] = li[j * 256 + (l4 + 4 * v) * 16 + l15];
+    }
+    band_wave_sync();
+    for (int i = j + 1; i < NT; ++i) {
+        mfma_d4 w = mfma_d4{0.0, 0.0, 0.0, 0.0};
+        for (int kk = j; kk < i; ++kk) {
+            const double *xt = col + (kk - j) * 272;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                w = __builtin_amdgcn_mfma_f64_16x16x4f64(L[(size_t)(16 * i + l15) * NB + 16 * kk + 4 * q + l4], xt[(4 * q + l4) * 17 + l15], w, 0, 0, 0);
+        }
+        mfma_d4 x = mfma_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x = __builtin_amdgcn_mfma_f64_16x16x4f64(-li[i * 256 + l15 * 16 + 4 * q + l4], w[q], x, 0, 0, 0);
+        double *t = col + (i - j) * 272;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) t[(l4 + 4 * v) * 17 + l15] = x[v];
+        band_wave_sync();
+    }
+    // the block column to memory, zeros above the diagonal tile (the sweeps read whole rows)
+    for (int i = 0; i < NT; ++i) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int r = l4 + 4 * v;
+            double val = 0.0;
+            if (i >= j) val = col[(i - j) * 272 + r * 17 + l15];
+            if (i == j && l15 > r) val = 0.0;
+            X[(size_t)(16 * i + r) * NB + 16 * j + l15] = val;
+        }
+    }
+}
+
+#define BA_BCR_SWEEP_THREADS 1024
+template <int NT>
+__global__ __launch_bounds__(BA_BCR_SWEEP_THREADS) void k_bcr_fwd(const BcrElim *__restrict__ elims, const int32_t *__restrict__ pend_ptr,
+                                                 const int32_t *__restrict__ pend, const double *__restrict__ Xf,
                                                  const double *__restrict__ G, double *__restrict__ bv,
-                                                 const double *__restrict__ Linv16, const int32_t *__restrict__ pos_f,
-                                                 const double *__restrict__ rin, const double *__restrict__ done) {
-    constexpr int NB = 16 * NT, LDL = NB + 1, WAVES = BA_BCR_BACK_THREADS / 64, CPL = (NB + 63) / 64;
-    extern __shared__ double bcr_smem[];
-    double *sL = bcr_smem;             // NB x (NB + 1): L_k, a row per lane in the substitution (padded: no bank conflicts)
-    double *sLi = sL + NB * LDL;       // NT x 256: inverses of its diagonal tiles
-    double *srhs = sLi + NT * 256;     // NB
-    double *sx = srhs + NB;            // 16
+                                                 const int32_t *__restrict__ pos_f, const double *__restrict__ rin,
+                                                 const double *__restrict__ done) {
+    constexpr int NB = 16 * NT, WAVES = BA_BCR_SWEEP_THREADS / 64, RPW = (NB + WAVES - 1) / WAVES, CPL = (NB + 63) / 64;
+    __shared__ double sb[NB];
     if (done && *done != 0.0) return;
     const BcrElim el = elims[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const size_t nb2 = (size_t)NB * NB;
-    {
-        const double *L = Lf + el.k * nb2, *li = Linv16 + (size_t)el.k * NT * 256;
-        for (int e = tid; e < NB * NB; e += BA_BCR_BACK_THREADS) {
-            const int r = e / NB, c = e - r * NB;
-            sL[r * LDL + c] = L[e];
-        }
-        for (int e = tid; e < NT * 256; e += BA_BCR_BACK_THREADS) sLi[e] = li[e];
-    }
-    if (tid < NB) {
-        const int fcam = tid < 6 * (NB / 6) ? pos_f[el.k * (NB / 6) + tid / 6] : -1;
-        srhs[tid] = fcam >= 0 ? rin[(size_t)6 * fcam + tid % 6] : 0.0;
-    }
-    __syncthreads();
-    // pending updates: wave wv takes rows wv, wv + WAVES, ...; lanes across the columns
+    // b = r_k - sum W y: wave wv takes rows wv, wv + WAVES, ...; lanes across the columns; one reduction per row at the end
+    double acc[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) acc[i] = 0.0;
     const int p0 = pend_ptr[el.k], p1 = pend_ptr[el.k + 1];
-    for (int r = wv; r < NB; r += WAVES) {
-        double sum = 0.0;
-        for (int q = p0; q < p1; ++q) {
-            const double *W = G + (size_t)pend[2 * q] * nb2 + (size_t)r * NB, *y = bv + (size_t)pend[2 * q + 1] * NB;
-            double part = 0.0;
+    for (int q = p0; q < p1; ++q) {
+        const double *W = G + (size_t)pend[2 * q] * nb2, *y = bv + (size_t)pend[2 * q + 1] * NB;
+        double yv[CPL];
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) {
-                const int col = lane + 64 * c;
-                if (col < NB) part = fma(W[col], y[col], part);
-            }
-            sum += wave_sum_dpp(part);
+        for (int c = 0; c < CPL; ++c) yv[c] = lane + 64 * c < NB ? y[lane + 64 * c] : 0.0;
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int r = wv + WAVES * i;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c)
+                if (r < NB && lane + 64 * c < NB) acc[i] = fma(W[(size_t)r * NB + lane + 64 * c], yv[c], acc[i]);
         }
-        if (lane == 0 && p1 > p0) srhs[r] -= sum;
+    }
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int r = wv + WAVES * i;
+        const double s = wave_sum_dpp(acc[i]);
+        if (lane == 0 && r < NB) {
+            const int fcam = r < 6 * (NB / 6) ? pos_f[el.k * (NB / 6) + r / 6] : -1;
+            sb[r] = (fcam >= 0 ? rin[(size_t)6 * fcam + r % 6] : 0.0) - s;
+        }
     }
     __syncthreads();
-    for (int s = 0; s < NT; ++s) {
-        if (tid < 16) {
-            const double *li = sLi + s * 256;   // y_s = Linv_s rhs_s
-            double sum = 0.0;
+    // y = X b (X lower triangular, zeros stored above the diagonal)
+    const double *X = Xf + el.k * nb2;
+    double bc[CPL];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sum = fma(li[tid * 16 + r], srhs[16 * s + r], sum);
-            sx[tid] = sum;
-        }
-        __syncthreads();
-        if (tid >= 16 * s + 16 && tid < NB) {
-            double sum = 0.0;
+    for (int c = 0; c < CPL; ++c) bc[c] = lane + 64 * c < NB ? sb[lane + 64 * c] : 0.0;
+    double part[RPW];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) sum = fma(sL[tid * LDL + 16 * s + i], sx[i], sum);
-            srhs[tid] -= sum;
-        } else if (tid >= 16 * s && tid < 16 * s + 16) {
-            srhs[tid] = sx[tid - 16 * s];
-        }
-        __syncthreads();
+    for (int i = 0; i < RPW; ++i) {
+        const int r = wv + WAVES * i;
+        part[i] = 0.0;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c)
+            if (r < NB && lane + 64 * c < NB) part[i] = fma(X[(size_t)r * NB + lane + 64 * c], bc[c], part[i]);
     }
-    if (tid < NB) bv[(size_t)el.k * NB + tid] = srhs[tid];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int r = wv + WAVES * i;
+        const double s = wave_sum_dpp(part[i]);
+        if (lane == 0 && r < NB) bv[(size_t)el.k * NB + r] = s;
+    }
+}
+
+// x_k = X_k^T (y_k - W_u^T x_u - W_v^T x_v): both products are TRANSPOSED ones -- lanes across the columns (coalesced rows),
+// the waves split the rows, their partial sums are joined through LDS in wave order
+template <int NT>
+__global__ __launch_bounds__(BA_BCR_SWEEP_THREADS) void k_bcr_backx(const BcrElim *__restrict__ elims, const double *__restrict__ Xf,
+                                                   const double *__restrict__ G, double *__restrict__ bv,
+                                                   const int32_t *__restrict__ pos_f, double *__restrict__ xout,
+                                                   const double *__restrict__ done) {
+    constexpr int NB = 16 * NT, WAVES = BA_BCR_SWEEP_THREADS / 64, RPW = (NB + WAVES - 1) / WAVES, CPL = (NB + 63) / 64;
+    __shared__ double sred[WAVES][NB];
+    __shared__ double st[NB];
+    if (done && *done != 0.0) return;
+    const BcrElim el = elims[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const size_t nb2 = (size_t)NB * NB;
+    const double yk = tid < NB ? bv[(size_t)el.k * NB + tid] : 0.0;
+    const int fcam = tid < 6 * (NB / 6) ? pos_f[el.k * (NB / 6) + tid / 6] : -1;
+    double part[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) part[c] = 0.0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int g = q ? el.gv : el.gu;
+        if (g < 0) continue;
+        const double *W = G + g * nb2, *xn = bv + (size_t)(q ? el.v : el.u) * NB;
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int r = wv + WAVES * i;
+            const double xr = r < NB ? xn[r] : 0.0;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c)
+                if (r < NB && lane + 64 * c < NB) part[c] = fma(W[(size_t)r * NB + lane + 64 * c], xr, part[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CPL; ++c)
+        if (lane + 64 * c < NB) sred[wv][lane + 64 * c] = part[c];
+    __syncthreads();
+    if (tid < NB) {
+        double t = yk;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) t -= sred[w][tid];
+        st[tid] = t;
+    }
+    __syncthreads();
+    const double *X = Xf + el.k * nb2;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) part[c] = 0.0;
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int r = wv + WAVES * i;
+        const double tr = r < NB ? st[r] : 0.0;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c)
+            if (r < NB && lane + 64 * c < NB) part[c] = fma(X[(size_t)r * NB + lane + 64 * c], tr, part[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < CPL; ++c)
+        if (lane + 64 * c < NB) sred[wv][lane + 64 * c] = part[c];
+    __syncthreads();
+    if (tid < NB) {
+        double x = 0.0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) x += sred[w][tid];
+        bv[(size_t)el.k * NB + tid] = x;
+        if (fcam >= 0) xout[(size_t)6 * fcam + tid % 6] = x;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ launch
@@ -925,9 +1036,6 @@ template <int NT>
 inline hipError_t bcr_set_attr() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bcr_factor<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)bcr_factor_lds_bytes(NT));
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bcr_fwd<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)bcr_fwd_lds_bytes(NT));
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void *>(k_bcr_back<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)bcr_back_lds_bytes(NT));
@@ -969,21 +1077,39 @@ inline hipError_t bcr_solve_launch_t(hipStream_t st, const BcrPlan &P, const Bcr
     return hipGetLastError();
 }
 
-// z = M^-1 r through the factors of the last bcr_solve_launch (r, z: vectors over the free cameras)
+// X_k = L_k^-1 for every block, after bcr_solve_launch (once per factorisation that is going to be used as a preconditioner)
+template <int NT>
+inline hipError_t bcr_invert_launch_t(hipStream_t st, const BcrPlan &P, const BcrDev &d) {
+    const size_t nb2 = (size_t)16 * NT * 16 * NT;
+    double *G = d.DG + (size_t)P.m * nb2, *Lf = G + (size_t)P.n_slots * nb2, *Xf = Lf + (size_t)P.m * nb2;
+    hipLaunchKernelGGL(k_bcr_inv<NT>, dim3(P.m), dim3(64 * NT), 0, st, Lf, d.linv, Xf);
+    return hipGetLastError();
+}
+inline hipError_t bcr_invert_launch(hipStream_t st, const BcrPlan &P, const BcrDev &d) {
+    switch (P.nt) {
+        case 2: return bcr_invert_launch_t<2>(st, P, d);
+        case 4: return bcr_invert_launch_t<4>(st, P, d);
+        case 6: return bcr_invert_launch_t<6>(st, P, d);
+        case 8: return bcr_invert_launch_t<8>(st, P, d);
+    }
+    return hipErrorInvalidValue;
+}
+
+// z = M^-1 r through the factors of the last bcr_solve_launch + bcr_invert_launch (r, z: vectors over the free cameras)
 template <int NT>
 inline hipError_t bcr_apply_launch_t(hipStream_t st, const BcrPlan &P, const BcrDev &d, const double *r, double *z, const double *done) {
     constexpr int NB = 16 * NT;
     const size_t nb2 = (size_t)NB * NB;
-    double *G = d.DG + (size_t)P.m * nb2, *Lf = G + (size_t)P.n_slots * nb2;
+    double *G = d.DG + (size_t)P.m * nb2, *Xf = G + (size_t)(P.n_slots + P.m) * nb2;
     const int nl = P.levels();
     for (int l = 0; l < nl; ++l) {
         const int ne_l = P.lvl_elim[l + 1] - P.lvl_elim[l];
-        hipLaunchKernelGGL(k_bcr_fwd<NT>, dim3(ne_l), dim3(BA_BCR_BACK_THREADS), bcr_fwd_lds_bytes(NT), st, d.elims + P.lvl_elim[l], d.pend_ptr,
-                           d.pend, Lf, G, d.bv, d.linv, d.pos_f, r, done);
+        hipLaunchKernelGGL(k_bcr_fwd<NT>, dim3(ne_l), dim3(BA_BCR_SWEEP_THREADS), 0, st, d.elims + P.lvl_elim[l], d.pend_ptr, d.pend, Xf, G, d.bv,
+                           d.pos_f, r, done);
     }
     for (int l = nl - 1; l >= 0; --l) {
         const int ne_l = P.lvl_elim[l + 1] - P.lvl_elim[l];
-        hipLaunchKernelGGL(k_bcr_back<NT>, dim3(ne_l), dim3(BA_BCR_BACK_THREADS), bcr_back_lds_bytes(NT), st, d.elims + P.lvl_elim[l], Lf, G, d.bv, d.linv, d.pos_f, z, done);
+        hipLaunchKernelGGL(k_bcr_backx<NT>, dim3(ne_l), dim3(BA_BCR_SWEEP_THREADS), 0, st, d.elims + P.lvl_elim[l], Xf, G, d.bv, d.pos_f, z, done);
     }
     return hipGetLastError();
 }

@@ -758,6 +758,7 @@ int do_bcr_pcg(BaHandle *h, int *iters_out, bool *ok) {
     const int nb_cam = (nf + 255) / 256, nb_row = (nf + 3) / 4;
     const BcrDev d = bcr_dev(h);
     HIPCHK(bcr_solve_launch(st, h->bcr_plan, d, h->S, h->gred, h->pz.p));   // factors of M, z0 = M^-1 (-g)
+    HIPCHK(bcr_invert_launch(st, h->bcr_plan, d));                           // X_k = L_k^-1: the sweeps below are matrix-vector products
     HIPCHK(hipMemsetAsync(h->pcg_sc.p, 0, sizeof(PcgScalars), st));
     PcgPartials pp{};
     {
@@ -1819,6 +1820,33 @@ int ba_debug_stamps(BaHandle *h, unsigned long long *out, long long capacity) {
     }
     h->stamps.release();
     return e;
+}
+
+// Diagnostic only (not in include/ba_hip.h): the cyclic reduction's preconditioner path against its direct solve.
+// After a build on a pattern with an exact schedule: x = the fused factor + solve of S x = -g, then the explicit inverses
+// and z = M^-1 (-g) through the sweeps (k_bcr_inv, k_bcr_fwd, k_bcr_backx).  *rel = max |x - z| / max |x| (0 when equal).
+int ba_debug_bcr_apply(BaHandle *h, double *rel) {
+    if (!h || !rel) return fail(BA_ERR_INVALID, "null argument");
+    if (int eu = usable(h)) return eu;
+    (void)hipSetDevice(h->device);
+    if (!h->built) return fail(BA_ERR_INVALID, "ba_build has not run");
+    int e;
+    if ((e = bcr_plan_for(h))) return e;
+    if (h->bcr_state != 1) return fail(BA_ERR_UNSUPPORTED, "the pattern has no cyclic-reduction schedule");
+    const int n = h->sym.n_free * 6;
+    const BcrDev d = bcr_dev(h);
+    HIPCHK(bcr_solve_launch(h->stream, h->bcr_plan, d, h->S, h->gred, h->px.p));
+    HIPCHK(bcr_invert_launch(h->stream, h->bcr_plan, d));
+    hipLaunchKernelGGL(k_negate, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, h->gred, h->pr.p);
+    HIPCHK(bcr_apply_launch(h->stream, h->bcr_plan, d, h->pr.p, h->pz.p, nullptr));
+    std::vector<double> x(n), z(n);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(x.data(), h->px.p, n * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(z.data(), h->pz.p, n * sizeof(double), hipMemcpyDeviceToHost));
+    double dmax = 0.0, xmax = 0.0;
+    for (int i = 0; i < n; ++i) { dmax = std::max(dmax, std::fabs(x[i] - z[i])); xmax = std::max(xmax, std::fabs(x[i])); }
+    *rel = xmax > 0.0 ? dmax / xmax : dmax;
+    return BA_OK;
 }
 
 int ba_synchronize(BaHandle *h) {

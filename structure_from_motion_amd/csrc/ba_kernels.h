@@ -1234,6 +1234,10 @@ __global__ void k_reduce_max(int n, const double *__restrict__ in, double *__res
 }
 
 __global__ void k_add_scalar(double *p, double v) { *p += v; }
+__global__ void k_negate(int n, const double *__restrict__ in, double *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = -in[i];
+}
 __global__ void k_copy_scalar(const double *src, double *dst) { *dst = *src; }
 // *out = NaN when *bad is set (an index was out of range), else unchanged
 __global__ void k_nan_if(const int *bad, double *out) {

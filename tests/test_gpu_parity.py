@@ -892,3 +892,18 @@ def test_chain_plus_revisits_cg_preconditioned_by_cyclic_reduction(gpu, kind):
     np.testing.assert_allclose(out["auto"][1].cam_pose, out["pcg"][1].cam_pose, rtol=1e-4, atol=1e-5)
     print("%s + revisits: AUTO %d CG iterations over %d LM steps (%.1f ms), block-Jacobi PCG %d (%.1f ms)"
           % (kind, sa["pcg_iterations"], sa["iterations"], sa["t_solve_ms"], sp["pcg_iterations"], sp["t_solve_ms"]))
+
+
+def test_cyclic_reduction_preconditioner_sweeps_equal_its_direct_solve(gpu):
+    """The preconditioner path of the cyclic reduction -- explicit inverses X_k = L_k^-1 (k_bcr_inv), forward sweep with the
+    plan's pending lists, backward sweep, all dense matrix-vector products -- applied to -g gives what the fused factor +
+    solve gives: every block size (2, 4, 6, 8 tiles), chains and a closed ring."""
+    cases = [synthetic.make_street(101, 3000, 8000, seed=62, outlier_frac=0.01, max_track=4),
+             synthetic.make_street(120, 3000, 10000, seed=61, outlier_frac=0.01, max_track=9),
+             synthetic.make_street(203, 5000, 22000, seed=51, outlier_frac=0.01),
+             synthetic.make_ring(400, 20000, seed=72, mean_track=6.0, max_track=18, n_fixed=2, outlier_frac=0.01, radius=60.0,
+                                 point_radius=(4.0, 20.0))]
+    for p in cases:
+        with _capi.Handle(_capi.Arrays.from_dict(p), loss="huber", f_scale=1.0) as h:
+            h.build(1e-3)
+            assert h.debug_bcr_apply() < 1e-9
