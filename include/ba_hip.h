@@ -188,7 +188,8 @@ int ba_analyze(const BaProblem *prob, BaAnalysis *out);
  * | lvl_elim[levels+1] | lvl_op[levels+1] | elims[5 each: k, gu, gv, u, v] | ops[9 each: kind, dst, a0, b0, a1, b1, k0,
  * k1, init] | n_rest | pend_ptr[m+1] | pend[2 * pend_ptr[m]] (per block the right-hand-side updates it has received by the
  * time it is eliminated, as (coupling slot, source block) pairs: the forward substitution of a NEW right-hand side through
- * the stored factors).  ok = 0 (only the header is written): the pattern is neither a chain nor a ring of bandwidth <= 21
+ * the stored factors) | lvl_fwd[levels+1] | fwd[6 each: block, a0, k0, a1, k1, flags] (the same sweep level by level as
+ * the GPU runs it: csrc/ba_bcr.h, BcrPlan::fwd).  ok = 0 (only the header is written): the pattern is neither a chain nor a ring of bandwidth <= 21
  * cameras.  What the tests execute with NumPy to check the schedule against a dense solve.  (No reference counterpart:
  * the reference leaves the linear algebra to scipy.) */
 int ba_bcr_plan(int32_t n_free, const int32_t *pairs, int64_t n_pairs, int32_t *out, int64_t capacity, int64_t *needed);

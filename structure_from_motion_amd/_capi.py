@@ -181,6 +181,8 @@ def bcr_plan(n_free, pairs, allow_rest=False):
     plan["n_rest"] = int(take(1)[0])
     plan["pend_ptr"] = take(m + 1)
     plan["pend"] = take(2 * int(plan["pend_ptr"][-1])).reshape(-1, 2)
+    plan["lvl_fwd"] = take(levels + 1)
+    plan["fwd"] = take(6 * int(plan["lvl_fwd"][-1])).reshape(-1, 6)
     assert at[0] == len(w)
     return plan
 

@@ -78,6 +78,12 @@ struct BcrPlan {
     // forward substitution of a NEW right-hand side through the stored factors (k_bcr_fwd): per block the updates it
     // has received by the time it is eliminated, b_k -= W[slot] y_j, as (slot, j) pairs in schedule order
     std::vector<int32_t> pend_ptr, pend;   // [m + 1], [2 * n]
+    // the same sweep as the GPU runs it (k_bcr_fwd), one launch per level: tasks of level l = the blocks eliminated at l
+    // (solve y = X (r - acc)) and the other survivors of level l - 1's eliminations, all of which first add the updates
+    // of level l - 1 to their running sum acc.  6 words per task: block, slot a0, source k0, slot a1 (-1: none), source
+    // k1, flags (1: first update of the block -- acc is written, not added to; 2: eliminated at this level -- solve;
+    // 4: no update at all -- acc counts as zero)
+    std::vector<int32_t> lvl_fwd, fwd;     // [levels + 1] offsets (in tasks), [6 * n_tasks]
     int levels() const { return (int)lvl_elim.size() - 1; }
 };
 
@@ -393,6 +399,31 @@ inline bool bcr_plan_with_order(int nf, const int64_t *keys, size_t nk, const st
         P.pend.clear();
         for (int b = 0; b < m; ++b) P.pend.insert(P.pend.end(), pl[b].begin(), pl[b].end());
     }
+    // forward tasks per level (k_bcr_fwd)
+    {
+        const int nl = (int)P.lvl_elim.size() - 1;
+        std::vector<char> touched(m, 0);
+        P.lvl_fwd.assign(1, 0);
+        P.fwd.clear();
+        for (int l = 0; l < nl; ++l) {
+            std::vector<char> elim_now(m, 0), listed(m, 0);
+            for (int e = P.lvl_elim[l]; e < P.lvl_elim[l + 1]; ++e) elim_now[P.elims[e].k] = 1;
+            if (l > 0)
+                for (int o = P.lvl_op[l - 1]; o < P.lvl_op[l]; ++o) {
+                    const BcrOp &op = P.ops[o];
+                    if (op.kind != 0) continue;
+                    const int32_t fl = (touched[op.dst] ? 0 : 1) | (elim_now[op.dst] ? 2 : 0);
+                    P.fwd.insert(P.fwd.end(), {op.dst, op.a0, op.k0, op.a1, op.k1, fl});
+                    touched[op.dst] = 1;
+                    listed[op.dst] = 1;
+                }
+            for (int e = P.lvl_elim[l]; e < P.lvl_elim[l + 1]; ++e) {
+                const int k = P.elims[e].k;
+                if (!listed[k]) P.fwd.insert(P.fwd.end(), {k, -1, -1, -1, -1, 2 | (touched[k] ? 0 : 4)});
+            }
+            P.lvl_fwd.push_back((int32_t)(P.fwd.size() / 6));
+        }
+    }
     P.ok = true;
     return true;
 }
@@ -438,7 +469,7 @@ inline bool bcr_make_plan(int nf, const int64_t *keys, size_t nk, BcrPlan &P, bo
 // the first one's write-back (they may not even be resident together), so the factor goes to a block of its own
 // (and m more for the explicit inverses X_k = L_k^-1 of the preconditioner sweeps, k_bcr_inv)
 inline size_t bcr_matrix_doubles(const BcrPlan &P) { return (size_t)(3 * P.m + P.n_slots) * P.nb * P.nb; }
-inline size_t bcr_vec_doubles(const BcrPlan &P) { return (size_t)P.m * P.nb; }
+inline size_t bcr_vec_doubles(const BcrPlan &P) { return (size_t)2 * P.m * P.nb; }   // block vectors + the forward sweep's running sums
 inline size_t bcr_linv_doubles(const BcrPlan &P) { return (size_t)P.m * P.nt * 256; }
 #ifndef BA_BCR_BACK_THREADS
 #define BA_BCR_BACK_THREADS 1024   // threads of k_bcr_back: 256 / 512 / 1024 measured, 0.439 / 0.408 / 0.390 ms per solve (Venice shape)
@@ -890,25 +921,30 @@ __global__ __launch_bounds__(64 * NT) void k_bcr_inv(const double *__restrict__ 
 }
 
 #define BA_BCR_SWEEP_THREADS 1024
+// One forward level: task t = (block d, up to two updates of the previous level, flags) -- acc_d (+)= W[a0] y[k0] + W[a1] y[k1],
+// and for a block eliminated at this level y_d = X_d (r_d - acc_d).  Every workgroup streams at most three 128 x 128
+// matrices: the launch is as short as the shortest chain allows, whatever the level.
 template <int NT>
-__global__ __launch_bounds__(BA_BCR_SWEEP_THREADS) void k_bcr_fwd(const BcrElim *__restrict__ elims, const int32_t *__restrict__ pend_ptr,
-                                                 const int32_t *__restrict__ pend, const double *__restrict__ Xf,
-                                                 const double *__restrict__ G, double *__restrict__ bv,
+__global__ __launch_bounds__(BA_BCR_SWEEP_THREADS) void k_bcr_fwd(const int32_t *__restrict__ tasks, const double *__restrict__ Xf,
+                                                 const double *__restrict__ G, double *__restrict__ bv, double *__restrict__ bacc,
                                                  const int32_t *__restrict__ pos_f, const double *__restrict__ rin,
                                                  const double *__restrict__ done) {
     constexpr int NB = 16 * NT, WAVES = BA_BCR_SWEEP_THREADS / 64, RPW = (NB + WAVES - 1) / WAVES, CPL = (NB + 63) / 64;
     __shared__ double sb[NB];
     if (done && *done != 0.0) return;
-    const BcrElim el = elims[blockIdx.x];
+    const int32_t *tk = tasks + 6 * blockIdx.x;
+    const int d = tk[0], flags = tk[5];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const size_t nb2 = (size_t)NB * NB;
-    // b = r_k - sum W y: wave wv takes rows wv, wv + WAVES, ...; lanes across the columns; one reduction per row at the end
+    // wave wv takes rows wv, wv + WAVES, ...; lanes across the columns; one DPP reduction per row
     double acc[RPW];
 #pragma unroll
     for (int i = 0; i < RPW; ++i) acc[i] = 0.0;
-    const int p0 = pend_ptr[el.k], p1 = pend_ptr[el.k + 1];
-    for (int q = p0; q < p1; ++q) {
-        const double *W = G + (size_t)pend[2 * q] * nb2, *y = bv + (size_t)pend[2 * q + 1] * NB;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int slot = tk[1 + 2 * q], src = tk[2 + 2 * q];
+        if (slot < 0) continue;
+        const double *W = G + (size_t)slot * nb2, *y = bv + (size_t)src * NB;
         double yv[CPL];
 #pragma unroll
         for (int c = 0; c < CPL; ++c) yv[c] = lane + 64 * c < NB ? y[lane + 64 * c] : 0.0;
@@ -920,18 +956,24 @@ __global__ __launch_bounds__(BA_BCR_SWEEP_THREADS) void k_bcr_fwd(const BcrElim 
                 if (r < NB && lane + 64 * c < NB) acc[i] = fma(W[(size_t)r * NB + lane + 64 * c], yv[c], acc[i]);
         }
     }
+    const bool solve = (flags & 2) != 0;
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
         const int r = wv + WAVES * i;
-        const double s = wave_sum_dpp(acc[i]);
+        double s = wave_sum_dpp(acc[i]);
         if (lane == 0 && r < NB) {
-            const int fcam = r < 6 * (NB / 6) ? pos_f[el.k * (NB / 6) + r / 6] : -1;
-            sb[r] = (fcam >= 0 ? rin[(size_t)6 * fcam + r % 6] : 0.0) - s;
+            if (!(flags & 1) && !(flags & 4)) s += bacc[(size_t)d * NB + r];     // (earlier levels' updates)
+            if (!(flags & 4) && !solve) bacc[(size_t)d * NB + r] = s;
+            if (solve) {
+                const int fcam = r < 6 * (NB / 6) ? pos_f[d * (NB / 6) + r / 6] : -1;
+                sb[r] = (fcam >= 0 ? rin[(size_t)6 * fcam + r % 6] : 0.0) - ((flags & 4) ? 0.0 : s);
+            }
         }
     }
+    if (!solve) return;   // (uniform: the task's flags)
     __syncthreads();
     // y = X b (X lower triangular, zeros stored above the diagonal)
-    const double *X = Xf + el.k * nb2;
+    const double *X = Xf + d * nb2;
     double bc[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) bc[c] = lane + 64 * c < NB ? sb[lane + 64 * c] : 0.0;
@@ -948,7 +990,7 @@ __global__ __launch_bounds__(BA_BCR_SWEEP_THREADS) void k_bcr_fwd(const BcrElim 
     for (int i = 0; i < RPW; ++i) {
         const int r = wv + WAVES * i;
         const double s = wave_sum_dpp(part[i]);
-        if (lane == 0 && r < NB) bv[(size_t)el.k * NB + r] = s;
+        if (lane == 0 && r < NB) bv[(size_t)d * NB + r] = s;
     }
 }
 
@@ -1025,7 +1067,8 @@ struct BcrDev {
     const BcrElim *elims;
     const BcrOp *ops;
     const int32_t *src, *pos_f;
-    const int32_t *pend_ptr, *pend;   // forward substitution of a new right-hand side (k_bcr_fwd)
+    const int32_t *fwd;               // forward tasks of a new right-hand side (k_bcr_fwd), BcrPlan::fwd
+    double *bacc;                     // [m * nb] running sums of the forward sweep
     double *DG;      // bcr_matrix_doubles: m diagonal blocks, the coupling slots, then the m factors L_k
     double *bv;      // bcr_vec_doubles
     double *linv;    // bcr_linv_doubles
@@ -1103,8 +1146,8 @@ inline hipError_t bcr_apply_launch_t(hipStream_t st, const BcrPlan &P, const Bcr
     double *G = d.DG + (size_t)P.m * nb2, *Xf = G + (size_t)(P.n_slots + P.m) * nb2;
     const int nl = P.levels();
     for (int l = 0; l < nl; ++l) {
-        const int ne_l = P.lvl_elim[l + 1] - P.lvl_elim[l];
-        hipLaunchKernelGGL(k_bcr_fwd<NT>, dim3(ne_l), dim3(BA_BCR_SWEEP_THREADS), 0, st, d.elims + P.lvl_elim[l], d.pend_ptr, d.pend, Xf, G, d.bv,
+        const int nt_l = P.lvl_fwd[l + 1] - P.lvl_fwd[l];
+        hipLaunchKernelGGL(k_bcr_fwd<NT>, dim3(nt_l), dim3(BA_BCR_SWEEP_THREADS), 0, st, d.fwd + 6 * (size_t)P.lvl_fwd[l], Xf, G, d.bv, d.bacc,
                            d.pos_f, r, done);
     }
     for (int l = nl - 1; l >= 0; --l) {

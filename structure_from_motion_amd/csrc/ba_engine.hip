@@ -711,8 +711,7 @@ int bcr_plan_for(BaHandle *h) {
     h->bcr_off[1] = put(P.ops.data(), P.ops.size() * sizeof(BcrOp) / 4);
     h->bcr_off[2] = put(P.src.data(), P.src.size());
     h->bcr_off[3] = put(P.pos_f.data(), P.pos_f.size());
-    h->bcr_off[4] = put(P.pend_ptr.data(), P.pend_ptr.size());
-    h->bcr_off[5] = put(P.pend.data(), P.pend.size());
+    h->bcr_off[4] = put(P.fwd.data(), P.fwd.size());
     HIPCHK(h->bcr_tab.upload(tab, h->stream));
     HIPCHK(h->bcr_dg.alloc(bcr_matrix_doubles(P)));
     HIPCHK(h->bcr_bv.alloc(bcr_vec_doubles(P)));
@@ -729,9 +728,8 @@ BcrDev bcr_dev(BaHandle *h) {
     d.ops = reinterpret_cast<const BcrOp *>(t + h->bcr_off[1]);
     d.src = t + h->bcr_off[2];
     d.pos_f = t + h->bcr_off[3];
-    d.pend_ptr = t + h->bcr_off[4];
-    d.pend = t + h->bcr_off[5];
-    d.DG = h->bcr_dg.p; d.bv = h->bcr_bv.p; d.linv = h->bcr_linv.p; d.info = h->dense_info.p;
+    d.fwd = t + h->bcr_off[4];
+    d.DG = h->bcr_dg.p; d.bv = h->bcr_bv.p; d.bacc = h->bcr_bv.p + (size_t)h->bcr_plan.m * h->bcr_plan.nb; d.linv = h->bcr_linv.p; d.info = h->dense_info.p;
     return d;
 }
 int do_bcr(BaHandle *h, bool *launched) {
@@ -1466,6 +1464,8 @@ static int bcr_plan_serialise(int32_t n_free, const int32_t *pairs, int64_t n_pa
             w.push_back((int32_t)std::min<int64_t>(P.n_rest, INT32_MAX));
             w.insert(w.end(), P.pend_ptr.begin(), P.pend_ptr.end());
             w.insert(w.end(), P.pend.begin(), P.pend.end());
+            w.insert(w.end(), P.lvl_fwd.begin(), P.lvl_fwd.end());
+            w.insert(w.end(), P.fwd.begin(), P.fwd.end());
         }
         *needed = (int64_t)w.size();
         if (out) {

@@ -120,6 +120,28 @@ def _apply(plan, keep, r):
             for slot, j in plan["pend"][plan["pend_ptr"][k]:plan["pend_ptr"][k + 1]]:
                 b -= G[slot] @ bv[j]
             bv[k] = np.linalg.solve(L[k], b)
+    # the same forward sweep as the GPU runs it: per level the task list (running sums per block, solve when eliminated)
+    bv2, acc = np.zeros((m, nb)), np.full((m, nb), np.nan)
+    for lv in range(plan["levels"]):
+        done_now = {}
+        for d, a0, k0, a1, k1, fl in plan["fwd"][plan["lvl_fwd"][lv]:plan["lvl_fwd"][lv + 1]]:
+            s = np.zeros(nb)
+            for a, ky in ((a0, k0), (a1, k1)):
+                if a >= 0:
+                    s += G[a] @ bv2[ky]
+            if not (fl & 1) and not (fl & 4):
+                s += acc[d]
+            if not (fl & 4) and not (fl & 2):
+                acc[d] = s
+            if fl & 2:
+                b = np.zeros(nb)
+                for o, f in enumerate(plan["pos_f"][d]):
+                    if f >= 0:
+                        b[6 * o:6 * o + 6] = r[6 * f:6 * f + 6]
+                done_now[d] = np.linalg.solve(L[d], b - (0.0 if fl & 4 else s))
+        for d, y in done_now.items():          # (a level's results become visible to the NEXT level's tasks)
+            bv2[d] = y
+    np.testing.assert_allclose(bv2, bv, rtol=0, atol=1e-12 * max(1.0, np.abs(bv).max()))
     z = np.zeros(len(r))
     for lv in range(plan["levels"] - 1, -1, -1):
         for k, gu, gv, u, v in plan["elims"][plan["lvl_elim"][lv]:plan["lvl_elim"][lv + 1]]:
