@@ -937,6 +937,23 @@ __global__ __launch_bounds__(BA_BCR_SWEEP_THREADS) void k_bcr_fwd(const int32_t 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const size_t nb2 = (size_t)NB * NB;
     // wave wv takes rows wv, wv + WAVES, ...; lanes across the columns; one DPP reduction per row
+    const bool solve = (flags & 2) != 0;
+    // every trip to memory of the launch is started here (a launch is a chain of dependent round trips otherwise: the
+    // running sums and the right-hand side behind the reductions, the rows of X behind the barrier)
+    const double *X = Xf + d * nb2;
+    double xw[RPW][CPL], old[RPW], rr[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int r = wv + WAVES * i, rc = r < NB ? r : 0;
+        old[i] = (!(flags & 1) && !(flags & 4)) ? bacc[(size_t)d * NB + rc] : 0.0;
+        rr[i] = 0.0;
+        if (solve) {
+            const int fcam = rc < 6 * (NB / 6) ? pos_f[d * (NB / 6) + rc / 6] : -1;
+            rr[i] = fcam >= 0 ? rin[(size_t)6 * fcam + rc % 6] : 0.0;
+        }
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) xw[i][c] = (solve && r < NB && lane + 64 * c < NB) ? X[(size_t)r * NB + lane + 64 * c] : 0.0;
+    }
     double acc[RPW];
 #pragma unroll
     for (int i = 0; i < RPW; ++i) acc[i] = 0.0;
@@ -956,35 +973,27 @@ __global__ __launch_bounds__(BA_BCR_SWEEP_THREADS) void k_bcr_fwd(const int32_t 
                 if (r < NB && lane + 64 * c < NB) acc[i] = fma(W[(size_t)r * NB + lane + 64 * c], yv[c], acc[i]);
         }
     }
-    const bool solve = (flags & 2) != 0;
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
         const int r = wv + WAVES * i;
-        double s = wave_sum_dpp(acc[i]);
+        const double s = wave_sum_dpp(acc[i]) + old[i];     // (old: the earlier levels' updates, zero when there are none)
         if (lane == 0 && r < NB) {
-            if (!(flags & 1) && !(flags & 4)) s += bacc[(size_t)d * NB + r];     // (earlier levels' updates)
             if (!(flags & 4) && !solve) bacc[(size_t)d * NB + r] = s;
-            if (solve) {
-                const int fcam = r < 6 * (NB / 6) ? pos_f[d * (NB / 6) + r / 6] : -1;
-                sb[r] = (fcam >= 0 ? rin[(size_t)6 * fcam + r % 6] : 0.0) - ((flags & 4) ? 0.0 : s);
-            }
+            if (solve) sb[r] = rr[i] - ((flags & 4) ? 0.0 : s);
         }
     }
     if (!solve) return;   // (uniform: the task's flags)
     __syncthreads();
     // y = X b (X lower triangular, zeros stored above the diagonal)
-    const double *X = Xf + d * nb2;
     double bc[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) bc[c] = lane + 64 * c < NB ? sb[lane + 64 * c] : 0.0;
     double part[RPW];
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
-        const int r = wv + WAVES * i;
         part[i] = 0.0;
 #pragma unroll
-        for (int c = 0; c < CPL; ++c)
-            if (r < NB && lane + 64 * c < NB) part[i] = fma(X[(size_t)r * NB + lane + 64 * c], bc[c], part[i]);
+        for (int c = 0; c < CPL; ++c) part[i] = fma(xw[i][c], bc[c], part[i]);
     }
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
@@ -1010,6 +1019,15 @@ __global__ __launch_bounds__(BA_BCR_SWEEP_THREADS) void k_bcr_backx(const BcrEli
     const size_t nb2 = (size_t)NB * NB;
     const double yk = tid < NB ? bv[(size_t)el.k * NB + tid] : 0.0;
     const int fcam = tid < 6 * (NB / 6) ? pos_f[el.k * (NB / 6) + tid / 6] : -1;
+    const double *X = Xf + el.k * nb2;
+    double xw[RPW][CPL];   // (the second product's rows, requested up front)
+#pragma unroll
+    for (int i = 0; i < RPW; ++i)
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int r = wv + WAVES * i;
+            xw[i][c] = (r < NB && lane + 64 * c < NB) ? X[(size_t)r * NB + lane + 64 * c] : 0.0;
+        }
     double part[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) part[c] = 0.0;
@@ -1038,7 +1056,6 @@ __global__ __launch_bounds__(BA_BCR_SWEEP_THREADS) void k_bcr_backx(const BcrEli
         st[tid] = t;
     }
     __syncthreads();
-    const double *X = Xf + el.k * nb2;
 #pragma unroll
     for (int c = 0; c < CPL; ++c) part[c] = 0.0;
 #pragma unroll
@@ -1046,8 +1063,7 @@ __global__ __launch_bounds__(BA_BCR_SWEEP_THREADS) void k_bcr_backx(const BcrEli
         const int r = wv + WAVES * i;
         const double tr = r < NB ? st[r] : 0.0;
 #pragma unroll
-        for (int c = 0; c < CPL; ++c)
-            if (r < NB && lane + 64 * c < NB) part[c] = fma(X[(size_t)r * NB + lane + 64 * c], tr, part[c]);
+        for (int c = 0; c < CPL; ++c) part[c] = fma(xw[i][c], tr, part[c]);
     }
 #pragma unroll
     for (int c = 0; c < CPL; ++c)
