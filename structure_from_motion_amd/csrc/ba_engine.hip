@@ -771,7 +771,7 @@ int do_bcr_pcg(BaHandle *h, int *iters_out, bool *ok) {
     const double tol2 = h->opt.pcg_tol * h->opt.pcg_tol;
     // (with a useful preconditioner CG converges in a handful of iterations; one that has not after BCR_PCG_CAP is no
     // help on this problem: the plan is dropped and block-Jacobi PCG takes over, this step and from now on)
-    constexpr int BCR_PCG_CAP = 60;
+    constexpr int BCR_PCG_CAP = 120;
     const int max_it = std::min(h->opt.pcg_max_iter > 0 ? h->opt.pcg_max_iter : 500, BCR_PCG_CAP);
     const double *done = &h->pcg_sc.p->done;
     if (!h->hpcg_pinned) HIPCHK(hipHostMalloc((void **)&h->hpcg_pinned, sizeof(PcgScalars), hipHostMallocDefault));

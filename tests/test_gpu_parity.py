@@ -885,7 +885,9 @@ def test_chain_plus_revisits_cg_preconditioned_by_cyclic_reduction(gpu, kind):
     out = _lm_paths(p, ("auto", "pcg"), 15, pcg_tol=1e-8, pcg_max_iter=3000)
     sa, sp = out["auto"][0], out["pcg"][0]
     assert sa["accepted"] >= 3 and sa["final_cost"] < 0.2 * sa["initial_cost"]
-    assert 0 < sa["pcg_iterations"] <= 45 * sa["iterations"], (sa["pcg_iterations"], sa["iterations"])   # (measured: 33 per step)
+    # (measured: 33 CG iterations per LM step on the ring, 49 on the open chain -- whose bending modes the revisits constrain --
+    # against 1 400 and more of block-Jacobi PCG)
+    assert 0 < sa["pcg_iterations"] <= 70 * sa["iterations"], (sa["pcg_iterations"], sa["iterations"])
     assert sp["pcg_iterations"] > 5 * sa["pcg_iterations"]
     assert sa["iterations"] == sp["iterations"]
     assert abs(sa["final_cost"] - sp["final_cost"]) <= 1e-6 * sp["final_cost"]
