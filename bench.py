@@ -129,7 +129,6 @@ def other_configs(_capi, synthetic):
     # f1: the incremental driver's growth (Fountain-shaped, visibility as Reconstruction.py records it): the problem with
     # 9 of its 11 images resident, then the last two images and their points arrive -- ba_append against a new handle
     try:
-        import numpy as np
         p = synthetic.make_config("fountain_sfm")
         m = p["obs_cam"] < 9
         npts = int(p["obs_pt"][m].max()) + 1
