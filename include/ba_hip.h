@@ -93,7 +93,13 @@ typedef struct BaOptions {
                               same inputs give the same bits, run after run, as the reference's single-threaded solve
                               does (BundleAdjustment.py:210-220).  Slower build pass; belongs to the analysed structure
                               (cannot change on a handle).  0 (default): the atomic kernels */
-    int32_t reserved;
+    int32_t schur_mode;    /* how the Schur complement is accumulated.  1 = chunks: inside the chunk's workgroup, pair groups reduced
+                              in registers, one flush per chunk (streets, rings: neighbouring points share their cameras);
+                              2 = rows: per-observation rows in HBM and one owner per block of S walking a global entry list,
+                              every block stored once, no atomics (csrc/ba_rows.h: unstructured co-visibility, where a chunk's
+                              pair groups hold hardly more than one entry each); 0 (default) = AUTO: chunks, unless the analysis
+                              finds fewer than three entries per group on average (BaAnalysis.auto_rows_mode).  Belongs to the
+                              analysed structure like `deterministic`, which always takes the chunks */
     double curv_floor;     /* Hessian weight of a residual component = max(rho' + 2 rho'' z, curv_floor * rho');
                               1.0 = plain IRLS, default 0.1 (in (0, 1]) */
 } BaOptions;
@@ -119,6 +125,9 @@ typedef struct BaAnalysis {
     int64_t n_direct_pairs, n_direct_cam_obs; /* contributions that bypass the LDS tiles */
     int32_t n_free_cams, n_observed_points, max_track, max_chunk_cams, max_chunk_pairs, n_heavy_points;
     double mean_track;
+    int64_t n_groups;        /* groups of eight pair entries over all chunks (chunk mode) */
+    int32_t auto_rows_mode;  /* 1: BaOptions.schur_mode = 0 takes the rows mode on this structure */
+    int32_t reserved;
 } BaAnalysis;
 
 typedef struct BaHandle BaHandle;

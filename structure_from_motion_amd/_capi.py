@@ -48,7 +48,7 @@ class BaOptions(C.Structure):
                 ("ftol", C.c_double), ("xtol", C.c_double), ("gtol", C.c_double),
                 ("lambda0", C.c_double), ("pcg_tol", C.c_double), ("pcg_max_iter", C.c_int32),
                 ("linear_solver", C.c_int32), ("verbose", C.c_int32), ("device", C.c_int32),
-                ("deterministic", C.c_int32), ("reserved", C.c_int32), ("curv_floor", C.c_double)]
+                ("deterministic", C.c_int32), ("schur_mode", C.c_int32), ("curv_floor", C.c_double)]
 
 
 class BaSummary(C.Structure):
@@ -67,7 +67,7 @@ class BaAnalysis(C.Structure):
                 ("nnz_blocks_full", C.c_int64), ("n_direct_pairs", C.c_int64), ("n_direct_cam_obs", C.c_int64),
                 ("n_free_cams", C.c_int32), ("n_observed_points", C.c_int32), ("max_track", C.c_int32),
                 ("max_chunk_cams", C.c_int32), ("max_chunk_pairs", C.c_int32), ("n_heavy_points", C.c_int32),
-                ("mean_track", C.c_double)]
+                ("mean_track", C.c_double), ("n_groups", C.c_int64), ("auto_rows_mode", C.c_int32), ("reserved", C.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -196,6 +196,8 @@ def default_options(**kw):
             v = LOSS[v]
         if k == "linear_solver" and isinstance(v, str):
             v = SOLVER[v]
+        if k == "schur_mode" and isinstance(v, str):
+            v = {"auto": 0, "chunks": 1, "rows": 2}[v]
         if not hasattr(o, k):
             raise TypeError(f"unknown option {k!r}")
         setattr(o, k, v)

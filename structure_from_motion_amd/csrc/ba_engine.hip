@@ -25,6 +25,7 @@
 #include "ba_kernels.h"
 #include "ba_heavy.h"
 #include "ba_det.h"
+#include "ba_rows.h"
 
 // ---- scratch of the no-allocation entry point (ba_eval_cost_noalloc, end of this file) ------------------------------
 // A file-scope device array instead of hipMalloc'd buffers: every GPU the library runs on holds its own copy (about
@@ -337,6 +338,11 @@ struct BaHandle {
     DevBuf<int> det_c_ptr, det_c_idx, det_s_ptr;
     DevBuf<unsigned> det_s_idx;
     DevBuf<double> det_cam_slab, det_blk_slab;
+    // rows mode (ba_rows.h): per-observation rows, global entry lists
+    DevBuf<double> rows_buf;
+    DevBuf<int> rw_ent, rw_xblk, rw_diag;
+    DevBuf<long long> rw_ptr;
+    int rw_nx = 0;
     DevBuf<double> dense_a;          // dense reduced system (one-workgroup solver, or the blocked multi-workgroup one)
     DevBuf<double> dense_linv;       // blocked solver: inverse factors of the diagonal blocks
     DevBuf<double> band_l, band_y, band_g, band_mid;  // block-banded factor, work vectors, separator system
@@ -516,6 +522,14 @@ int do_build(BaHandle *h, bool timed) {
     if (h->n_chunks > 0 && det) {
         if (h->opt.loss == BA_LOSS_HUBER) hipLaunchKernelGGL((k_build_det<BA_LOSS_HUBER>), dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, build_args(h), det_args(h));
         else hipLaunchKernelGGL((k_build_det<-1>), dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, build_args(h), det_args(h));
+    } else if (h->n_chunks > 0 && h->sym.rows) {
+        RowsArgs R{};
+        R.rows = h->rows_buf.p; R.ent = h->rw_ent.p; R.ptr = h->rw_ptr.p; R.key_slot = h->ck_pair_slot.p;
+        R.xblk = h->rw_xblk.p; R.diag_key = h->rw_diag.p; R.n_x = h->rw_nx;
+        if (h->opt.loss == BA_LOSS_HUBER) hipLaunchKernelGGL((k_lin<BA_LOSS_HUBER>), dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, build_args(h), h->rows_buf.p);
+        else hipLaunchKernelGGL((k_lin<-1>), dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, build_args(h), h->rows_buf.p);
+        if (nf > 0) hipLaunchKernelGGL(k_rows_diag, dim3(nf), dim3(256), 0, st, R, h->S, h->U, h->gc, h->gred);
+        if (h->rw_nx > 0) hipLaunchKernelGGL(k_rows_cross, dim3((h->rw_nx + 127) / 128), dim3(256), 0, st, R, h->S);
     } else if (h->n_chunks > 0) {
         BuildArgs A = build_args(h);
         if (h->stamps.n) {
@@ -1017,6 +1031,7 @@ int check_options(BaOptions &o) {
     if (!(o.pcg_tol > 0.0)) o.pcg_tol = 1e-8;
     if (!(o.curv_floor > 0.0) || o.curv_floor > 1.0) o.curv_floor = 0.1;
     o.deterministic = o.deterministic ? 1 : 0;
+    if (o.schur_mode < 0 || o.schur_mode > 2) return fail(BA_ERR_INVALID, "schur_mode must be 0 (auto), 1 (chunks) or 2 (rows)");
     return BA_OK;
 }
 
@@ -1059,9 +1074,15 @@ int alloc_work(BaHandle *h) {
 int build_structure(BaHandle *h, const HostProblem &hp, int n_cams, int n_points, int64_t n_obs) {
     int e;
     const char *msg = "";
-    if ((e = analyze_structure(n_cams, n_points, n_obs, hp.cam_fixed.data(), hp.obs_cam.data(), hp.obs_pt.data(), h->sym, &msg,
-                               h->opt.deterministic != 0)))
+    // BaOptions.schur_mode: 0 AUTO (chunks; rows when the chunk-local groups are mostly padding), 1 chunks, 2 rows
+    const bool det = h->opt.deterministic != 0;
+    const bool rows_forced = h->opt.schur_mode == 2 && !det;
+    if ((e = analyze_structure(n_cams, n_points, n_obs, hp.cam_fixed.data(), hp.obs_cam.data(), hp.obs_pt.data(), h->sym, &msg, det, rows_forced)))
         return fail(e, "%s", msg);
+    if (h->opt.schur_mode == 0 && wants_rows_mode(h->sym) && (double)n_obs * ROW_DOUBLES * 8 < 16e9) {
+        if ((e = analyze_structure(n_cams, n_points, n_obs, hp.cam_fixed.data(), hp.obs_cam.data(), hp.obs_pt.data(), h->sym, &msg, false, true)))
+            return fail(e, "%s", msg);
+    }
     const bool tm_on = getenv("BA_TIME") != nullptr;
     double tl = now_ms();
     finalize_pattern(h->sym, {});
@@ -1092,7 +1113,27 @@ int build_structure(BaHandle *h, const HostProblem &hp, int n_cams, int n_points
     }
     HIPCHK(h->pair_entries.upload(s.pair_entries, st));
     HIPCHK(h->ck_pgrp.upload(s.ck_pgrp, st));
-    if (tm_on) { fprintf(stderr, "[create]   %-22s %7.2f ms\n", "index uploads", now_ms() - tl); tl = now_ms(); }
+    h->rw_nx = 0;
+    if (s.rows) {
+        std::vector<int32_t> xblk, diag((size_t)std::max(s.n_free, 1), -1);
+        for (size_t k = 0; k < s.raw_keys.size(); ++k) {
+            const int i = (int)(s.raw_keys[k] >> 32), j = (int)(s.raw_keys[k] & 0xffffffff);
+            if (i == j) diag[i] = (int32_t)k;
+            else xblk.push_back((int32_t)k);
+        }
+        h->rw_nx = (int)xblk.size();
+        if (xblk.empty()) xblk.push_back(0);
+        std::vector<long long> ptr(s.rw_ptr.begin(), s.rw_ptr.end());
+        if (s.rw_ent.empty()) s.rw_ent.assign(2, 0);
+        HIPCHK(h->rw_ent.upload(s.rw_ent, st));
+        HIPCHK(h->rw_ptr.upload(ptr, st));
+        HIPCHK(h->rw_xblk.upload(xblk, st));
+        HIPCHK(h->rw_diag.upload(diag, st));
+        HIPCHK(h->rows_buf.alloc_grow((size_t)std::max<int64_t>(s.n_obs, 1) * ROW_DOUBLES));
+    } else {
+        h->rows_buf.release(); h->rw_ent.release(); h->rw_ptr.release(); h->rw_xblk.release(); h->rw_diag.release();
+    }
+    if (tm_on) { fprintf(stderr, "[create]   %-22s %7.2f ms%s\n", "index uploads", now_ms() - tl, s.rows ? "  (rows mode)" : ""); tl = now_ms(); }
     const int ea = alloc_work(h);
     if (tm_on) fprintf(stderr, "[create]   %-22s %7.2f ms\n", "work buffers", now_ms() - tl);
     return ea;
@@ -1141,7 +1182,7 @@ int append_tail(BaHandle *h, const HostProblem &hp, int nc2, int np2, int64_t no
     *done = false;
     Symbolic &s = h->sym;
     const int64_t no1 = s.n_obs;
-    if (s.n_heavy > 0 || no2 == no1) return BA_OK;
+    if (s.n_heavy > 0 || no2 == no1 || s.rows) return BA_OK;   // (rows mode: the entry lists are global -- rebuilt)
     // points seen before (by the handle's observations)
     std::vector<uint8_t> seen((size_t)np2, 0);
     for (int i = 0; i < s.n_pts_obs; ++i) seen[s.pt_order[i]] = 1;
@@ -1351,6 +1392,7 @@ int ba_set_values(BaHandle *h, const BaProblem *prob, const BaOptions *opt) {
     if (opt) {
         o = *opt;
         o.device = h->opt.device;
+        o.schur_mode = h->opt.schur_mode;   // (part of the analysed structure)
         if ((e = check_options(o))) return e;
         if (o.deterministic != h->opt.deterministic)
             return fail(BA_ERR_INVALID, "ba_set_values: BaOptions.deterministic belongs to the analysed structure and cannot change on a handle");
@@ -1392,6 +1434,7 @@ int ba_append(BaHandle *h, const BaProblem *grown, const BaOptions *opt, int32_t
     if (opt) {
         o = *opt;
         o.device = h->opt.device;
+        o.schur_mode = h->opt.schur_mode;
         if ((e = check_options(o))) return e;
         if (o.deterministic != h->opt.deterministic)
             return fail(BA_ERR_INVALID, "ba_append: BaOptions.deterministic belongs to the analysed structure and cannot change on a handle");
@@ -1810,7 +1853,7 @@ int ba_debug_stamps(BaHandle *h, unsigned long long *out, long long capacity) {
     if (int eu = usable(h)) return eu;
     (void)hipSetDevice(h->device);
     if (capacity < (long long)h->n_chunks * 12) return fail(BA_ERR_INVALID, "stamp buffer too small");
-    if (h->opt.deterministic) return fail(BA_ERR_UNSUPPORTED, "no stamped variant of the deterministic build");
+    if (h->opt.deterministic || h->sym.rows) return fail(BA_ERR_UNSUPPORTED, "no stamped variant of the deterministic build or of the rows mode");
     HIPCHK(h->stamps.alloc((size_t)h->n_chunks * 12));
     HIPCHK(hipMemset(h->stamps.p, 0, (size_t)h->n_chunks * 12 * 8));
     int e = do_build(h, false);
@@ -1950,6 +1993,8 @@ int ba_analyze(const BaProblem *prob, BaAnalysis *out) {
     out->max_chunk_cams = s.max_chunk_cams;
     out->max_chunk_pairs = s.max_chunk_pairs;
     out->mean_track = s.mean_track;
+    out->n_groups = s.n_groups;
+    out->auto_rows_mode = wants_rows_mode(s) ? 1 : 0;
     return BA_OK;
 }
 

@@ -31,12 +31,13 @@ void parallel_for(int64_t n, F fn) {
 }  // namespace
 
 int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *cam_fixed,
-                      const int32_t *obs_cam, const int32_t *obs_pt, Symbolic &s, const char **err, bool deterministic) {
+                      const int32_t *obs_cam, const int32_t *obs_pt, Symbolic &s, const char **err, bool deterministic, bool rows) {
     const bool tm_on = getenv("BA_TIME") != nullptr;
     auto tm_t0 = std::chrono::steady_clock::now();
     auto tick = [&](const char *what) { if (tm_on) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[symbolic] %-22s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(t - tm_t0).count()); tm_t0 = t; } };
     s = Symbolic();
     s.deterministic = deterministic;
+    s.rows = rows && !deterministic;
     // longest track on the chunk path (longer: heavy point).  The atomic-free build has no path for a camera without a
     // local slot, so there a point must fit the slots of one chunk.
     const int max_chunk_track = deterministic ? CHUNK_CAMS_WIDE : CHUNK_OBS;
@@ -154,6 +155,105 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
         track_sum += L;
     }
     tick("obs gather");
+    if (s.rows) {
+        // --- rows mode: chunks of whole points by observation / point count only; the Schur entries are global ------
+        s.ck_obs.push_back(0);
+        s.ck_pt.push_back(0);
+        int cur_obs = 0, cur_pts = 0;
+        for (int i = 0; i < s.n_pts_chunked; ++i) {
+            const int L = (int)(pstart[i + 1] - pstart[i]);
+            if (cur_pts > 0 && (cur_obs + L > CHUNK_OBS || cur_pts + 1 > CHUNK_PTS)) {
+                s.ck_obs.push_back((int32_t)pstart[i]);
+                s.ck_pt.push_back(i);
+                cur_obs = cur_pts = 0;
+            }
+            cur_obs += L;
+            cur_pts += 1;
+        }
+        if (cur_pts > 0) {
+            s.ck_obs.push_back((int32_t)pstart[s.n_pts_chunked]);
+            s.ck_pt.push_back(s.n_pts_chunked);
+        }
+        const size_t nck = s.ck_obs.size() - 1;
+        s.ck_cam.assign(nck + 1, 0);
+        s.ck_pair.assign(nck + 1, 0);
+        s.ck_pe.assign(nck + 1, 0);
+        s.ck_pgrp.assign(nck, 0);
+        parallel_for(pstart[s.n_pts_chunked], [&](int64_t lo, int64_t hi) {
+            for (int64_t k = lo; k < hi; ++k) s.o_lcam[k] = s.cam_free[s.o_cam[k]] < 0 ? -2 : -1;
+        });
+        tick("chunking (rows)");
+        // entries by block row: observations inside a point are sorted by camera, and free indices grow with the camera
+        // index, so (a <= c) gives fa <= fc: the entry belongs to the upper block (fa, fc) as T_a T_c^T
+        const int nf = s.n_free;
+        std::vector<int64_t> rstart((size_t)nf + 1, 0);
+        for (int i = 0; i < s.n_pts_chunked; ++i) {
+            const int64_t b = pstart[i], e = pstart[i + 1];
+            for (int64_t a = b; a < e; ++a) {
+                const int fa = s.cam_free[s.o_cam[a]];
+                if (fa < 0) continue;
+                for (int64_t c = a; c < e; ++c) {
+                    const int fc = s.cam_free[s.o_cam[c]];
+                    if (fc < 0) continue;
+                    rstart[fa + 1] += (c != a && fc == fa) ? 2 : 1;
+                }
+            }
+        }
+        for (int f = 0; f < nf; ++f) rstart[f + 1] += rstart[f];
+        const int64_t n_ent = rstart[nf];
+        struct Ent { int32_t fc, oi, oj; };
+        std::vector<Ent> ents((size_t)n_ent);
+        {
+            std::vector<int64_t> fill(rstart.begin(), rstart.end() - 1);
+            for (int i = 0; i < s.n_pts_chunked; ++i) {
+                const int64_t b = pstart[i], e = pstart[i + 1];
+                for (int64_t a = b; a < e; ++a) {
+                    const int fa = s.cam_free[s.o_cam[a]];
+                    if (fa < 0) continue;
+                    for (int64_t c = a; c < e; ++c) {
+                        const int fc = s.cam_free[s.o_cam[c]];
+                        if (fc < 0) continue;
+                        ents[fill[fa]++] = Ent{fc, (int32_t)a, (int32_t)c};
+                        if (c != a && fc == fa) ents[fill[fa]++] = Ent{fc, (int32_t)c, (int32_t)a};  // one camera, the point twice
+                    }
+                }
+            }
+        }
+        tick("row entries");
+        // each row sorted by column (stable: point order inside a block), rows dealt to host threads by entry count
+        {
+            const int T = (int)std::max<int64_t>(1, std::min<int64_t>(8, n_ent / 200000));
+            std::vector<std::thread> th;
+            auto work = [&](int t) {
+                const int64_t lo = n_ent * t / T, hi = n_ent * (t + 1) / T;
+                int f0 = (int)(std::lower_bound(rstart.begin(), rstart.end(), lo) - rstart.begin());
+                int f1 = (int)(std::lower_bound(rstart.begin(), rstart.end(), hi) - rstart.begin());
+                if (t == T - 1) f1 = nf;
+                for (int f = f0; f < f1 && f < nf; ++f)
+                    std::stable_sort(ents.begin() + rstart[f], ents.begin() + rstart[f + 1], [](const Ent &x, const Ent &y) { return x.fc < y.fc; });
+            };
+            if (T == 1) work(0);
+            else {
+                for (int t = 0; t < T; ++t) th.emplace_back(work, t);
+                for (auto &x : th) x.join();
+            }
+        }
+        tick("row sort");
+        s.rw_ent.resize((size_t)n_ent * 2);
+        s.rw_ptr.clear();
+        for (int f = 0; f < nf; ++f)
+            for (int64_t k = rstart[f]; k < rstart[f + 1]; ++k) {
+                if (k == rstart[f] || ents[k].fc != ents[k - 1].fc) {
+                    s.raw_keys.push_back(((int64_t)f << 32) | (uint32_t)ents[k].fc);
+                    s.rw_ptr.push_back(k);
+                }
+                s.rw_ent[2 * k] = ents[k].oi;
+                s.rw_ent[2 * k + 1] = ents[k].oj;
+            }
+        s.rw_ptr.push_back(n_ent);
+        s.n_pair_real = n_ent;
+        tick("row blocks");
+    } else {
     // --- greedy chunking -----------------------------------------------------------------
     // The point range is cut into up to CHUNK_THREADS parts (balanced by observations) that are chunked independently on
     // host threads and concatenated: a chunk never spans a seam, nothing else differs from one sequential sweep.  The
@@ -399,7 +499,9 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
         s.max_chunk_pairs = std::max(s.max_chunk_pairs, P.max_chunk_pairs);
         P = Part();
     }
+    s.raw_keys.swap(ck_pair_key);
     tick("chunking");
+    }   // (chunk mode)
     // --- heavy points (more observations than a chunk holds): one workgroup each (k_build_heavy), every (a <= c)
     // pair of the point's observations gets its block slot from a triangular list
     s.hv_obs.push_back(pstart[s.n_pts_chunked]);
@@ -425,22 +527,22 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
         s.hv_pair.push_back((int64_t)s.hv_keys.size());
     }
     tick("heavy points");
-    if (tm_on) {
+    if (!s.rows) {
         long long groups = 0, pairs = 0;
         for (size_t c = 0; c + 1 < s.ck_pair.size(); ++c) {
             const int np_ = s.ck_pair[c + 1] - s.ck_pair[c];
             groups += s.ck_pgrp[s.ck_pair[c] + c + np_];
             pairs += np_;
         }
-        fprintf(stderr, "[symbolic] chunks %zu, pairs %lld, groups %lld, real entries %lld (fill %.1f %% of the groups, %.1f %% of the padded rounds)\n",
+        s.n_groups = groups;
+        if (tm_on) fprintf(stderr, "[symbolic] chunks %zu, pairs %lld, groups %lld, real entries %lld (fill %.1f %% of the groups, %.1f %% of the padded rounds)\n",
                 s.ck_obs.size() - 1, pairs, groups, (long long)s.n_pair_real, 100.0 * s.n_pair_real / (groups * (double)PAIR_RUN),
                 100.0 * s.n_pair_real / (double)(s.pair_entries.size() - (size_t)(CHUNK_OBS / 2) * PAIR_RUN));
     }
     // (the build kernel prefetches one round of entries unconditionally: readable padding behind the last chunk)
     s.pair_entries.resize(s.pair_entries.size() + (size_t)(CHUNK_OBS / 2) * PAIR_RUN, PAIR_NULL);
     // slots are resolved by finalize_pattern (the pattern may be a union over ranks)
-    s.ck_pair_slot.assign(ck_pair_key.size(), -1);
-    s.raw_keys.swap(ck_pair_key);
+    s.ck_pair_slot.assign(s.raw_keys.size(), -1);
     s.mean_track = s.n_pts_obs ? track_sum / s.n_pts_obs : 0.0;
     return BA_OK;
 }

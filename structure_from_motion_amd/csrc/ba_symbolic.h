@@ -72,6 +72,15 @@ struct Symbolic {
     int64_t n_direct_pairs = 0, n_direct_cam_obs = 0;
     int max_chunk_cams = 0, max_chunk_pairs = 0;
     bool deterministic = false;      // analysed for the atomic-free build (see analyze_structure)
+    int64_t n_groups = 0;            // groups of pair entries over all chunks (chunk mode)
+    // "rows" mode (ba_rows.h): the Schur complement from GLOBAL per-block entry lists instead of chunk-local ones -- for
+    // co-visibility without structure inside a chunk (hardly two points of a chunk share a camera pair).  Chunks then only
+    // carry points and observations (no camera slots, no pairs); raw_keys holds every block (i <= j) that has an entry, in
+    // ascending order, ck_pair_slot its slot, and entries rw_ptr[k] .. rw_ptr[k + 1] of rw_ent the (observation i,
+    // observation j) pairs of block k, in point order (internal observation indices; T_i T_j^T goes to the block as stored).
+    bool rows = false;
+    std::vector<int32_t> rw_ent;     // 2 per entry
+    std::vector<int64_t> rw_ptr;     // [raw_keys.size() + 1]
 };
 
 // Contribution tables of the deterministic (atomic-free) build: every partial result of the build kernels has a slab
@@ -98,8 +107,15 @@ void build_det_tables(const Symbolic &s, DetTables &t);
 // Phase A: ordering + chunking + this problem's own pair keys.  Returns 0 or a BA_ERR_* code.
 // deterministic: the structure for the atomic-free build -- no chunk holds more cameras than it has local slots
 // (CHUNK_CAMS_WIDE), and a point seen by more cameras than that is a heavy point.
+// rows: the "rows" mode of the Schur complement (Symbolic::rows; never together with deterministic).
 int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *cam_fixed,
-                      const int32_t *obs_cam, const int32_t *obs_pt, Symbolic &s, const char **err, bool deterministic = false);
+                      const int32_t *obs_cam, const int32_t *obs_pt, Symbolic &s, const char **err, bool deterministic = false,
+                      bool rows = false);
+// AUTO's rule for the rows mode, from a chunk-mode analysis: the chunk-local groups are mostly padding (fewer than three
+// real entries per group of eight on average) and the problem is large enough for it to matter.
+inline bool wants_rows_mode(const Symbolic &s) {
+    return !s.deterministic && !s.rows && s.n_pair_real >= 200000 && s.n_pair_real < 3 * s.n_groups;
+}
 // Phase B: final pattern = own keys U extra keys; resolves chunk-local pairs to block slots.
 void finalize_pattern(Symbolic &s, const std::vector<int64_t> &extra_keys);
 

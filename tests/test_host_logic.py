@@ -274,3 +274,19 @@ def test_analyze_camera_slots_of_wide_chunks():
     assert a["max_chunk_cams"] == 112 and a["n_heavy_points"] == 0
     assert a["n_direct_cam_obs"] == int(np.maximum(cnt - 112, 0).sum())     # (one point per chunk: its cameras past the 112th)
     assert a["n_pair_entries"] == int((cnt * (cnt + 1) // 2).sum())
+
+
+def test_analysis_says_when_auto_takes_the_rows_mode():
+    """AUTO's rule for the Schur accumulation (include/ba_hip.h, BaOptions.schur_mode): chunk-local pair groups that are
+    mostly padding -- fewer than three real entries per group of eight, on a problem with at least 200 k entries."""
+    street = _capi.analyze(_capi.Arrays.from_dict(synthetic.make_street(60, 9000, 40000, seed=2)))
+    assert street["auto_rows_mode"] == 0 and street["n_pair_entries"] > 3 * street["n_groups"] > 0
+    rnd = synthetic.make_ring(300, 9000, seed=5, K=(1200.0, 1200.0, 960.0, 540.0), visibility="random", mean_track=8.0, max_track=12,
+                              n_fixed=2, radius=6.0, noise=0.5)
+    a = _capi.analyze(_capi.Arrays.from_dict(rnd))
+    assert a["auto_rows_mode"] == 1 and 200000 <= a["n_pair_entries"] < 3 * a["n_groups"]
+    small = synthetic.make_ring(40, 900, seed=12, visibility="random", mean_track=5.0, max_track=9, n_fixed=2, radius=6.0, noise=0.5)
+    assert _capi.analyze(_capi.Arrays.from_dict(small))["auto_rows_mode"] == 0     # too small to matter
+    with pytest.raises(TypeError):
+        _capi.default_options(schur_rows=1)
+    assert _capi.default_options(schur_mode="rows").schur_mode == 2

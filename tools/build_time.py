@@ -2,13 +2,15 @@
 import sys
 sys.path.insert(0, '/root/repo')
 from structure_from_motion_amd import _capi, synthetic
-for name in sys.argv[1:] or ["orbit1024"]:
+opts = {k: v for k, v in (a.split("=") for a in sys.argv[1:] if "=" in a)}   # e.g. schur_mode=rows deterministic=1
+opts = {k: (int(v) if v.isdigit() else v) for k, v in opts.items()}
+for name in [a for a in sys.argv[1:] if "=" not in a] or ["orbit1024"]:
     p = synthetic.make_config(name)
     arr = _capi.Arrays.from_dict(p)
     a = _capi.analyze(arr)
-    with _capi.Handle(arr, loss="huber", f_scale=1.0) as h:
+    with _capi.Handle(arr, loss="huber", f_scale=1.0, **opts) as h:
         h.build_bench(1e-4, warmup=0, reps=3)
         ms_pass, ms_k = h.build_bench(1e-4, warmup=0, reps=10)
-    print("%s: %d obs, chunks %d, pair entries %d, direct pairs %d, direct cam obs %d, max chunk cams %d: pass %.3f ms, k_build %.3f ms, %.3g obs/s" %
+    print(opts, "auto_rows_mode", a["auto_rows_mode"], "groups", a["n_groups"]); print("%s: %d obs, chunks %d, pair entries %d, direct pairs %d, direct cam obs %d, max chunk cams %d: pass %.3f ms, k_build %.3f ms, %.3g obs/s" %
           (name, len(p["obs_cam"]), a["n_chunks"], a["n_pair_entries"], a["n_direct_pairs"], a["n_direct_cam_obs"], a["max_chunk_cams"],
            ms_pass, ms_k, len(p["obs_cam"]) / ms_pass * 1e3), flush=True)
