@@ -233,12 +233,15 @@ def other_configs(_capi, synthetic):
     p = synthetic.make_config("orbit1024")
     n_unk = 6 * int((np.asarray(p["cam_fixed"]) == 0).sum())
     orbit = {"cameras": len(p["cam_pose"]), "observations": len(p["obs_cam"]), "unknowns": n_unk,
-             "solver": "auto = blocked dense Cholesky (full block pattern); pcg_tol_1e-8 forces block-Jacobi PCG"}
+             "solver": "auto = blocked dense Cholesky or block-Jacobi PCG, whichever the handle times as faster (full block pattern); pcg_tol_1e-8 forces block-Jacobi PCG"}
     for tag, kw in (("auto_dense_cholesky", {}), ("pcg_tol_1e-8", dict(linear_solver="pcg", pcg_tol=1e-8))):
         with _capi.Handle(_capi.Arrays.from_dict(p), loss="huber", f_scale=1.0, max_iter=300, **kw) as h:
             if "build_ms" not in orbit:
+                # (AUTO's build pass on this shape is the rows mode, csrc/ba_rows.h; the chunk kernel is timed beside it below)
                 h.build_bench(1e-4, warmup=0, reps=3)
-                orbit["build_ms"], _ = h.build_bench(1e-4, warmup=0, reps=10)
+                orbit["build_ms"], orbit["build_kernels_ms"] = h.build_bench(1e-4, warmup=0, reps=10)
+                orbit["build_obs_per_s"] = len(p["obs_cam"]) / orbit["build_ms"] * 1e3
+                orbit["build_mode"] = "rows" if _capi.analyze(h.arr)["auto_rows_mode"] else "chunks"
             h.run(1)
             h.synchronize()
             t0 = time.perf_counter()
@@ -253,6 +256,9 @@ def other_configs(_capi, synthetic):
             orbit[tag]["solve_ms_upper_bound"] = solve_s * 1e3
             orbit[tag]["fp64_mfma_tflops_lower_bound"] = n_unk ** 3 / 3.0 / solve_s / 1e12
             orbit[tag]["fp64_mfma_frac_of_78.6_lower_bound"] = n_unk ** 3 / 3.0 / solve_s / 78.6e12
+    with _capi.Handle(_capi.Arrays.from_dict(p), loss="huber", f_scale=1.0, schur_mode="chunks") as h:
+        h.build_bench(1e-4, warmup=0, reps=3)
+        orbit["build_ms_chunk_kernel_forced"], _ = h.build_bench(1e-4, warmup=0, reps=10)
     out["orbit1024"] = orbit
     return out
 

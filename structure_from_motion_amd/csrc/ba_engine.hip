@@ -516,7 +516,11 @@ int do_build(BaHandle *h, bool timed) {
     const size_t nred = (size_t)h->n_upper * 36 + (size_t)nf * 33 + 4;
     const bool det = h->opt.deterministic != 0;
     // (deterministic build: k_det_reduce writes every element of S, U, g_c, g_red -- only the sums and the tail are cleared)
+    // (rows mode: every block of S that has an entry is STORED by its owner; when these are all the blocks of the pattern -- no
+    // block that only another rank or a heavy point contributes to -- S needs no clearing either)
+    const bool rows_all = h->sym.rows && h->n_heavy == 0 && h->n_chunks > 0 && (int)h->sym.raw_keys.size() == h->n_upper;
     if (det) HIPCHK(hipMemsetAsync(h->red.p + nred - 4, 0, (4 + BA_MAX_WORLD) * sizeof(double), st));
+    else if (rows_all) HIPCHK(hipMemsetAsync(h->red.p + (size_t)h->n_upper * 36, 0, (nred - (size_t)h->n_upper * 36 + BA_MAX_WORLD) * sizeof(double), st));
     else HIPCHK(hipMemsetAsync(h->red.p, 0, (nred + BA_MAX_WORLD) * sizeof(double), st));
     if (timed) HIPCHK(hipEventRecord(h->ev0, st));
     if (h->n_chunks > 0 && det) {
@@ -524,10 +528,10 @@ int do_build(BaHandle *h, bool timed) {
         else hipLaunchKernelGGL((k_build_det<-1>), dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, build_args(h), det_args(h));
     } else if (h->n_chunks > 0 && h->sym.rows) {
         RowsArgs R{};
-        R.rows = h->rows_buf.p; R.ent = h->rw_ent.p; R.ptr = h->rw_ptr.p; R.key_slot = h->ck_pair_slot.p;
+        R.rows = h->rows_buf.p; R.tails = h->rows_buf.p + (size_t)std::max<int64_t>(h->sym.n_obs, 1) * ROW_A; R.ent = h->rw_ent.p; R.ptr = h->rw_ptr.p; R.key_slot = h->ck_pair_slot.p;
         R.xblk = h->rw_xblk.p; R.diag_key = h->rw_diag.p; R.n_x = h->rw_nx;
-        if (h->opt.loss == BA_LOSS_HUBER) hipLaunchKernelGGL((k_lin<BA_LOSS_HUBER>), dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, build_args(h), h->rows_buf.p);
-        else hipLaunchKernelGGL((k_lin<-1>), dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, build_args(h), h->rows_buf.p);
+        if (h->opt.loss == BA_LOSS_HUBER) hipLaunchKernelGGL((k_lin<BA_LOSS_HUBER>), dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, build_args(h), R.rows, R.tails);
+        else hipLaunchKernelGGL((k_lin<-1>), dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, build_args(h), R.rows, R.tails);
         if (nf > 0) hipLaunchKernelGGL(k_rows_diag, dim3(nf), dim3(256), 0, st, R, h->S, h->U, h->gc, h->gred);
         if (h->rw_nx > 0) hipLaunchKernelGGL(k_rows_cross, dim3((h->rw_nx + 127) / 128), dim3(256), 0, st, R, h->S);
     } else if (h->n_chunks > 0) {

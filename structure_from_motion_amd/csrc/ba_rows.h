@@ -6,7 +6,8 @@
 // hold one entry of eight, and each of them is a 288-byte read-modify-write at the memory side (the object-centric
 // shape orbit1024: 2.6 M groups for 4.3 M entries, 746 MB of atomics per pass).  Here the pass is cut the other way:
 //   * k_lin: one chunk of whole points per workgroup (no camera slots, no pairs): residuals, weights, the point blocks
-//     V, g_p (LDS), their damped factor, and per observation ONE ROW of 24 doubles in HBM, written coalesced:
+//     V, g_p (LDS), their damped factor, and per observation a row of 16 doubles (128 bytes: one cache line per gather) and a
+//     tail of 8 in HBM, written coalesced:
 //         T' = Wt L^-T (9), Y = R X (3), w = T' u (3), and what the camera sums need: the projection derivatives a, b, p02,
 //         p12, the curvature weights wh (2) and the weighted residuals w r (2);
 //   * k_rows_cross: one lane pair per off-diagonal block (i < j) of S that has entries: it walks the block's entry list
@@ -24,10 +25,11 @@
 
 namespace ba {
 
-constexpr int ROW_DOUBLES = 24;
+constexpr int ROW_A = 16, ROW_B = 8, ROW_DOUBLES = ROW_A + ROW_B;   // rows of 128 B (one cache line per gather) + the camera-sum tails
 
 struct RowsArgs {
-    double *rows;                 // [n_obs * ROW_DOUBLES], internal observation order
+    double *rows;                 // [n_obs * ROW_A]: T' (9), Y (3), w (3), pad -- internal observation order, 128-byte rows
+    double *tails;                // [n_obs * ROW_B]: a, b, p02, p12, wh (2), w r (2)
     const int *ent;               // 2 per entry
     const long long *ptr;         // [n_keys + 1]
     const int *key_slot;          // block slot of each key (= ck_pair_slot in this mode)
@@ -37,7 +39,7 @@ struct RowsArgs {
 };
 
 template <int LOSS>
-__global__ __launch_bounds__(CHUNK_OBS) void k_lin(const BuildArgs A, double *__restrict__ rows) {
+__global__ __launch_bounds__(CHUNK_OBS) void k_lin(const BuildArgs A, double *__restrict__ rows, double *__restrict__ tails) {
     __shared__ __attribute__((aligned(16))) double sP[2][CHUNK_PTS * 9];   // per point: V (6), g_p (3) in two replicas; then L^-1 (6), u (3)
     __shared__ double sRed[8];
     const int ck = blockIdx.x, tid = threadIdx.x;
@@ -147,11 +149,13 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_lin(const BuildArgs A, double *__
         }
         const double w0 = t[0] * u0 + t[1] * u1 + t[2] * u2, w1 = t[3] * u0 + t[4] * u1 + t[5] * u2,
                      w2 = t[6] * u0 + t[7] * u1 + t[8] * u2;
-        double2 *d = reinterpret_cast<double2 *>(rows + (size_t)oo * ROW_DOUBLES);
+        double2 *d = reinterpret_cast<double2 *>(rows + (size_t)oo * ROW_A);
         d[0] = make_double2(t[0], t[1]); d[1] = make_double2(t[2], t[3]); d[2] = make_double2(t[4], t[5]);
         d[3] = make_double2(t[6], t[7]); d[4] = make_double2(t[8], Yr[0]); d[5] = make_double2(Yr[1], Yr[2]);
-        d[6] = make_double2(w0, w1); d[7] = make_double2(w2, tail[0]); d[8] = make_double2(tail[1], tail[2]);
-        d[9] = make_double2(tail[3], tail[4]); d[10] = make_double2(tail[5], tail[6]); d[11] = make_double2(tail[7], 0.0);
+        d[6] = make_double2(w0, w1); d[7] = make_double2(w2, 0.0);
+        double2 *q = reinterpret_cast<double2 *>(tails + (size_t)oo * ROW_B);
+        q[0] = make_double2(tail[0], tail[1]); q[1] = make_double2(tail[2], tail[3]);
+        q[2] = make_double2(tail[4], tail[5]); q[3] = make_double2(tail[6], tail[7]);
     }
 }
 
@@ -179,7 +183,7 @@ __device__ __forceinline__ void schur_entry(const double *__restrict__ Ti, const
 }
 
 __device__ __forceinline__ void load_row12(const double *__restrict__ rows, int o, double *__restrict__ T, double *__restrict__ Y) {
-    const double2 *q = reinterpret_cast<const double2 *>(rows + (size_t)o * ROW_DOUBLES);
+    const double2 *q = reinterpret_cast<const double2 *>(rows + (size_t)o * ROW_A);
     const double2 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3], v4 = q[4], v5 = q[5];
     T[0] = v0.x; T[1] = v0.y; T[2] = v1.x; T[3] = v1.y; T[4] = v2.x; T[5] = v2.y; T[6] = v3.x; T[7] = v3.y; T[8] = v4.x;
     Y[0] = v4.y; Y[1] = v5.x; Y[2] = v5.y;
@@ -248,14 +252,15 @@ __global__ __launch_bounds__(256) void k_rows_diag(const RowsArgs R, double *__r
         load_row12(R.rows, v.y, Tj, Yj);
         schur_entry(Ti, Yi, Tj, Yj, acc);
         if (v.x == v.y) {
-            const double2 *q = reinterpret_cast<const double2 *>(R.rows + (size_t)v.x * ROW_DOUBLES);
-            const double2 t6 = q[6], t7 = q[7], t8 = q[8], t9 = q[9], t10 = q[10], t11 = q[11];
+            const double2 *q = reinterpret_cast<const double2 *>(R.rows + (size_t)v.x * ROW_A);
+            const double2 *qt = reinterpret_cast<const double2 *>(R.tails + (size_t)v.x * ROW_B);
+            const double2 t6 = q[6], t7 = q[7], t8 = qt[0], t9 = qt[1], t10 = qt[2], t11 = qt[3];
             const double w0 = t6.x, w1 = t6.y, w2 = t7.x;
             gr[0] += Yi[1] * w2 - Yi[2] * w1;
             gr[1] += Yi[2] * w0 - Yi[0] * w2;
             gr[2] += Yi[0] * w1 - Yi[1] * w0;
             gr[3] += w0; gr[4] += w1; gr[5] += w2;
-            const double a = t7.y, b = t8.x, p02 = t8.y, p12 = t9.x, wh0 = t9.y, wh1 = t10.x, wr0 = t10.y, wr1 = t11.x;
+            const double a = t8.x, b = t8.y, p02 = t9.x, p12 = t9.y, wh0 = t10.x, wh1 = t10.y, wr0 = t11.x, wr1 = t11.y;
             // the camera block of the observation as linearize forms it in the local rotation tangent: P (-[Y]x) | P
             double Jc[2][6];
             Jc[0][0] = p02 * Yi[1]; Jc[0][1] = a * Yi[2] - p02 * Yi[0]; Jc[0][2] = -a * Yi[1];

@@ -1,5 +1,5 @@
 """Developer: one workload for rocprofv3 (kernel trace or a PMC pass).
-usage: prof_run.py <config> [det] [lm=<steps>] [solver=<name>] [builds=<n>]"""
+usage: prof_run.py <config> [det] [lm=<steps>] [solver=<name>] [builds=<n>] [schur_mode=auto|chunks|rows]"""
 import sys
 sys.path.insert(0, '/root/repo')
 from structure_from_motion_amd import _capi, synthetic
@@ -12,6 +12,8 @@ if "solver" in kw:
     opts["linear_solver"] = kw["solver"]
 if "pcg_tol" in kw:
     opts["pcg_tol"] = float(kw["pcg_tol"])
+if "schur_mode" in kw:
+    opts["schur_mode"] = kw["schur_mode"]
 with _capi.Handle(_capi.Arrays.from_dict(p), **opts) as h:
     ms_pass, ms_k = h.build_bench(1e-4, warmup=2, reps=int(kw.get("builds", 10)))
     print("%s det=%d: build pass %.3f ms, chunk kernel %.3f ms" % (name, det, ms_pass, ms_k), flush=True)
