@@ -1,6 +1,6 @@
 """Randomised differential test: the HIP engine against the NumPy oracle on small problems with irregular structure
 (random visibility, duplicate observations, random gauge, unobserved points, more cameras per chunk than LDS tiles,
-every scipy loss).  Tolerances as in test_gpu_parity.py."""
+every scipy loss), in both modes of the build pass (chunk kernel, rows mode).  Tolerances as in test_gpu_parity.py."""
 import numpy as np
 import pytest
 
@@ -49,8 +49,9 @@ def random_problem(rng):
     return dict(cam_pose=cam_pose, cam_intr=cam_intr, cam_fixed=fixed, points=pts, obs_cam=oc, obs_pt=op, obs_xy=xy)
 
 
+@pytest.mark.parametrize("schur_mode", ["chunks", "rows"])
 @pytest.mark.parametrize("seed", range(24))
-def test_random_structure_against_oracle(gpu, seed):
+def test_random_structure_against_oracle(gpu, seed, schur_mode):
     rng = np.random.default_rng(1000 + seed)
     p = random_problem(rng)
     loss = O.LOSSES[seed % len(O.LOSSES)]
@@ -64,7 +65,7 @@ def test_random_structure_against_oracle(gpu, seed):
         return
     nb = O.normal_blocks(*args, p["obs_xy"], fs, loss, floor=1.0)
     S, gred, _, _, _ = O.reduced_system(nb, p["cam_fixed"], p["obs_cam"], p["obs_pt"], lam)
-    with _capi.Handle(arr, loss=loss, f_scale=fs) as h:
+    with _capi.Handle(arr, loss=loss, f_scale=fs, schur_mode=schur_mode) as h:
         h.build(lam)
         r = h.reduced_system()
         free = p["cam_fixed"] == 0
@@ -86,7 +87,7 @@ def test_random_structure_solve_invariants(gpu, seed):
     loss = O.LOSSES[seed % len(O.LOSSES)]
     solver = ["auto", "pcg", "dense_cholesky"][seed % 3]
     arr = _capi.Arrays.from_dict(p)
-    s = _capi.solve(arr, loss=loss, f_scale=1.0, max_iter=40, linear_solver=solver)
+    s = _capi.solve(arr, loss=loss, f_scale=1.0, max_iter=40, linear_solver=solver, schur_mode=["auto", "rows"][(seed // 3) % 2])
     assert s["status"] >= 0
     assert s["final_cost"] <= s["initial_cost"] * (1 + 1e-12)
     f = O.residuals(arr.cam_pose, p["cam_intr"], arr.points, p["obs_cam"], p["obs_pt"], p["obs_xy"])

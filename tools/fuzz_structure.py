@@ -49,6 +49,7 @@ def problem(rng):
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+schur_mode = sys.argv[3] if len(sys.argv) > 3 else "auto"   # auto | chunks | rows
 bad = 0
 for seed in range(seed0, seed0 + n_cases):
     rng = np.random.default_rng(seed)
@@ -60,7 +61,7 @@ for seed in range(seed0, seed0 + n_cases):
     args = (p["cam_pose"], p["cam_intr"], p["points"], p["obs_cam"], p["obs_pt"])
     nb = O.normal_blocks(*args, p["obs_xy"], 1.0, loss, floor=1.0)
     S, gred, _, _, _ = O.reduced_system(nb, p["cam_fixed"], p["obs_cam"], p["obs_pt"], lam)
-    with _capi.Handle(arr, loss=loss, f_scale=1.0) as h:
+    with _capi.Handle(arr, loss=loss, f_scale=1.0, schur_mode=schur_mode) as h:
         h.build(lam)
         r = h.reduced_system()
         free = p["cam_fixed"] == 0
