@@ -27,6 +27,10 @@ def _engine_problem():
     if os.environ.get("BA_TEST_PROBLEM") == "city_20th":
         # BASELINE.json config 5 at 1/20 of its points and observations, ALL of its 10 000 cameras (replicated on every rank)
         return synthetic.make_street(10000, 1_000_000, 5_000_000, seed=1233 + 5), 3
+    if os.environ.get("BA_TEST_PROBLEM") == "random60":
+        # unstructured co-visibility (the rows mode of the build pass when BA_TEST_SCHUR=rows)
+        return synthetic.make_ring(60, 2500, seed=31, K=(1200.0, 1200.0, 960.0, 540.0), focal_jitter=0.05, noise=0.5, outlier_frac=0.02,
+                                   visibility="random", mean_track=6.0, max_track=16, n_fixed=2, radius=6.0), 300
     return synthetic.make_ring(16, 600, seed=8, mean_track=4.0, outlier_frac=0.02), 80
 
 
@@ -93,7 +97,8 @@ def engine_sharded_solve(rank, world, port, out_dir):
     sh, pidx = badist.shard_points(p, rank, world)
     h = badist.create_sharded_handle(sh, rank, world, loss="huber", f_scale=1.0, max_iter=max_iter, device=0,
                                      verbose=int(os.environ.get("BA_TEST_VERBOSE", "0")),
-                                     deterministic=int(os.environ.get("BA_TEST_DET", "0")))
+                                     deterministic=int(os.environ.get("BA_TEST_DET", "0")),
+                                     schur_mode=os.environ.get("BA_TEST_SCHUR", "auto"))
     s = h.run()
     cp, pts = h.state()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), cp=cp, pts=pts, pidx=pidx, cost=s["final_cost"], status=s["status"],

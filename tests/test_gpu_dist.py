@@ -68,6 +68,24 @@ def test_sharded_solves_use_the_cyclic_reduction_beyond_the_dense_size(gpu, tmp_
         assert np.allclose(r[name + "_cp"], arr.cam_pose, rtol=1e-6, atol=1e-6)
 
 
+def test_two_ranks_in_the_rows_mode(gpu, tmp_path, monkeypatch):
+    """The rows mode of the build pass (csrc/ba_rows.h) on point shards: every rank stores the blocks its own points give --
+    the ranks' patterns differ, so S is cleared first and the all-reduce adds the shards up -- against the single handle."""
+    monkeypatch.setenv("BA_TEST_PROBLEM", "random60")
+    monkeypatch.setenv("BA_TEST_SCHUR", "rows")
+    p = synthetic.make_ring(60, 2500, seed=31, K=(1200.0, 1200.0, 960.0, 540.0), focal_jitter=0.05, noise=0.5, outlier_frac=0.02,
+                            visibility="random", mean_track=6.0, max_track=16, n_fixed=2, radius=6.0)
+    arr = _capi.Arrays.from_dict(p)
+    s = _capi.solve(arr, loss="huber", f_scale=1.0, max_iter=300, schur_mode="rows")
+    assert s["status"] > 0
+    mp.spawn(engine_sharded_solve, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert int(r0["status"]) == int(r1["status"]) and int(r0["status"]) > 0
+    np.testing.assert_array_equal(r0["cp"], r1["cp"])
+    assert abs(float(r0["cost"]) - s["final_cost"]) <= 1e-7 * s["final_cost"]
+    assert np.allclose(r0["cp"], arr.cam_pose, rtol=1e-5, atol=1e-5)
+
+
 def test_rank_without_observations_stays_in_step(gpu, tmp_path):
     mp.spawn(engine_sharded_empty_rank, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     r0, r1 = np.load(tmp_path / "empty0.npz"), np.load(tmp_path / "empty1.npz")
