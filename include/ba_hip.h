@@ -99,7 +99,8 @@ typedef struct BaOptions {
                               every block stored once, no atomics (csrc/ba_rows.h: unstructured co-visibility, where a chunk's
                               pair groups hold hardly more than one entry each); 0 (default) = AUTO: chunks, unless the analysis
                               finds fewer than three entries per group on average (BaAnalysis.auto_rows_mode).  Belongs to the
-                              analysed structure like `deterministic`, which always takes the chunks */
+                              analysed structure like `deterministic`; with deterministic = 1 the rows mode is taken as it is (its
+                              kernels have no atomics) unless the problem has heavy points, then the chunks */
     double curv_floor;     /* Hessian weight of a residual component = max(rho' + 2 rho'' z, curv_floor * rho');
                               1.0 = plain IRLS, default 0.1 (in (0, 1]) */
 } BaOptions;

@@ -423,7 +423,7 @@ int upload_pattern(BaHandle *h) {
     h->gc = h->U + nU;
     h->gred = h->gc + ng;
     h->sums = h->gred + ng;
-    if (h->opt.deterministic) {
+    if (h->opt.deterministic && !s.rows) {
         build_det_tables(s, h->det);
         const DetTables &t = h->det;
         {
@@ -444,7 +444,7 @@ int upload_pattern(BaHandle *h) {
 
 DetArgs det_args(BaHandle *h) {
     DetArgs D{};
-    if (!h->opt.deterministic) return D;
+    if (!h->opt.deterministic || h->sym.rows) return D;   // (the rows mode has no atomics to replace)
     D.cam_slab = h->det_cam_slab.p;
     D.blk_slab = h->det_blk_slab.p;
     D.ck_lg = h->det_ck_lg.p;
@@ -514,7 +514,7 @@ int do_build(BaHandle *h, bool timed) {
     hipStream_t st = h->stream;
     const int nf = h->sym.n_free;
     const size_t nred = (size_t)h->n_upper * 36 + (size_t)nf * 33 + 4;
-    const bool det = h->opt.deterministic != 0;
+    const bool det = h->opt.deterministic != 0 && !h->sym.rows;   // (the rows kernels are deterministic as they are)
     // (deterministic build: k_det_reduce writes every element of S, U, g_c, g_red -- only the sums and the tail are cleared)
     // (rows mode: every block of S that has an entry is STORED by its owner; when these are all the blocks of the pattern -- no
     // block that only another rank or a heavy point contributes to -- S needs no clearing either)
@@ -1078,15 +1078,16 @@ int alloc_work(BaHandle *h) {
 int build_structure(BaHandle *h, const HostProblem &hp, int n_cams, int n_points, int64_t n_obs) {
     int e;
     const char *msg = "";
-    // BaOptions.schur_mode: 0 AUTO (chunks; rows when the chunk-local groups are mostly padding), 1 chunks, 2 rows
+    // BaOptions.schur_mode: 0 AUTO (chunks; rows when the chunk-local groups are mostly padding), 1 chunks, 2 rows.
+    // deterministic + rows: only without heavy points (k_build_heavy adds to what the rows kernels stored with atomics).
     const bool det = h->opt.deterministic != 0;
-    const bool rows_forced = h->opt.schur_mode == 2 && !det;
-    if ((e = analyze_structure(n_cams, n_points, n_obs, hp.cam_fixed.data(), hp.obs_cam.data(), hp.obs_pt.data(), h->sym, &msg, det, rows_forced)))
-        return fail(e, "%s", msg);
-    if (h->opt.schur_mode == 0 && wants_rows_mode(h->sym) && (double)n_obs * ROW_DOUBLES * 8 < 16e9) {
-        if ((e = analyze_structure(n_cams, n_points, n_obs, hp.cam_fixed.data(), hp.obs_cam.data(), hp.obs_pt.data(), h->sym, &msg, false, true)))
-            return fail(e, "%s", msg);
-    }
+    auto analyse = [&](bool rows) -> int {
+        const int rc = analyze_structure(n_cams, n_points, n_obs, hp.cam_fixed.data(), hp.obs_cam.data(), hp.obs_pt.data(), h->sym, &msg, det, rows);
+        return rc ? fail(rc, "%s", msg) : BA_OK;
+    };
+    if ((e = analyse(h->opt.schur_mode == 2))) return e;
+    if (h->opt.schur_mode == 0 && wants_rows_mode(h->sym) && (double)n_obs * ROW_DOUBLES * 8 < 16e9 && (e = analyse(true))) return e;
+    if (det && h->sym.rows && h->sym.n_heavy > 0 && (e = analyse(false))) return e;
     const bool tm_on = getenv("BA_TIME") != nullptr;
     double tl = now_ms();
     finalize_pattern(h->sym, {});

@@ -6,7 +6,7 @@
 // hold one entry of eight, and each of them is a 288-byte read-modify-write at the memory side (the object-centric
 // shape orbit1024: 2.6 M groups for 4.3 M entries, 746 MB of atomics per pass).  Here the pass is cut the other way:
 //   * k_lin: one chunk of whole points per workgroup (no camera slots, no pairs): residuals, weights, the point blocks
-//     V, g_p (LDS), their damped factor, and per observation a row of 16 doubles (128 bytes: one cache line per gather) and a
+//     V, g_p (gathered per point in LDS), their damped factor, and per observation a row of 16 doubles (128 bytes: one cache line per gather) and a
 //     tail of 8 in HBM, written coalesced:
 //         T' = Wt L^-T (9), Y = R X (3), w = T' u (3), and what the camera sums need: the projection derivatives a, b, p02,
 //         p12, the curvature weights wh (2) and the weighted residuals w r (2);
@@ -15,9 +15,8 @@
 //     k_build's Schur phase does, and STORES the block -- every block is written once, by its owner, no atomics;
 //   * k_rows_diag: one workgroup per free camera: its observations (the entries of its diagonal block) give U, g_c, its part
 //     of the reduced gradient and the diagonal block, summed over the lanes in a fixed order.
-// Given the rows, every sum of the reduced system has a fixed order in this mode; the rows themselves come from per-point
-// sums that k_lin forms with LDS atomics, so two passes agree to rounding, not to the bit (BaOptions.deterministic takes
-// the chunk kernels of ba_det.h).
+// Every floating-point sum of these three kernels has a fixed order (k_lin gathers each point's sums over its consecutive
+// lanes): without heavy points two passes over the same state give the same bits.
 // The host builds the lists once per structure (analyze_structure(..., rows); Symbolic::rw_ent / rw_ptr).  Heavy points keep
 // their own kernel, which adds to S, U, g with atomics after these kernels have stored.
 #pragma once
@@ -40,7 +39,9 @@ struct RowsArgs {
 
 template <int LOSS>
 __global__ __launch_bounds__(CHUNK_OBS) void k_lin(const BuildArgs A, double *__restrict__ rows, double *__restrict__ tails) {
-    __shared__ __attribute__((aligned(16))) double sP[2][CHUNK_PTS * 9];   // per point: V (6), g_p (3) in two replicas; then L^-1 (6), u (3)
+    __shared__ __attribute__((aligned(16))) double sV[CHUNK_OBS * 9];      // per observation: its part of V (6), g_p (3)
+    __shared__ __attribute__((aligned(16))) double sP[CHUNK_PTS * 9];      // per point: L^-1 (6), u (3)
+    __shared__ int sStart[CHUNK_PTS + 1];                                  // first lane of each point's observations
     __shared__ double sRed[8];
     const int ck = blockIdx.x, tid = threadIdx.x;
     const int ob = A.ck_obs[ck], nobs = A.ck_obs[ck + 1] - ob;
@@ -50,16 +51,19 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_lin(const BuildArgs A, double *__
     const int oo = ob + (act ? tid : 0);
     const int cam = A.o_cam[oo];
     const int p = A.o_pt[oo];
+    const int p_prev = A.o_pt[oo > ob ? oo - 1 : oo];
     const double2 xy = reinterpret_cast<const double2 *>(A.o_xy)[oo];
     CamAux ca;
     load_aux_local(A.aux, cam, ca);
     const double X0 = A.points[3 * (size_t)p], X1 = A.points[3 * (size_t)p + 1], X2 = A.points[3 * (size_t)p + 2];
     const bool free_cam = A.cam_free[cam] >= 0;
-    for (int i = tid; i < npts * 9; i += CHUNK_OBS) { sP[0][i] = 0.0; sP[1][i] = 0.0; }
-    lds_barrier();
 
     double Wt[9], Yr[3], tail[8];
     const int lp = act ? p - pb : 0;
+    // the observations of a point are consecutive lanes: each point's sums are gathered by ONE lane in lane order (no
+    // atomics -- with the fixed order of the other two kernels every pass over the same state gives the same bits)
+    if (act && (tid == 0 || p != p_prev)) sStart[lp] = tid;
+    if (tid == 0) sStart[npts] = nobs;
     double cost_loc = 0.0;
     if (act) {
         ObsLin L;
@@ -87,19 +91,24 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_lin(const BuildArgs A, double *__
         // P = [[a, 0, p02], [0, b, p12]] (linearize): the camera block of the observation is P [-[Y]x | I]
         tail[0] = L.Jc[0][3]; tail[1] = L.Jc[1][4]; tail[2] = L.Jc[0][5]; tail[3] = L.Jc[1][5];
         tail[4] = L.wh[0]; tail[5] = L.wh[1]; tail[6] = wr0; tail[7] = wr1;
-        double *vp = sP[tid & 1] + lp * 9;
+        double *vp = &sV[tid * 9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) atomicAdd(&vp[k], vs[k]);
+        for (int k = 0; k < 9; ++k) vp[k] = vs[k];
     }
     lds_barrier();
 
     double gmax_loc = 0.0;
     if (tid < npts) {
-        double *vp = &sP[0][tid * 9];
-        const double *rp = &sP[1][tid * 9];
-        const double v00 = vp[0] + rp[0], v01 = vp[1] + rp[1], v02 = vp[2] + rp[2], v11 = vp[3] + rp[3], v12 = vp[4] + rp[4],
-                     v22 = vp[5] + rp[5];
-        const double g0 = vp[6] + rp[6], g1 = vp[7] + rp[7], g2 = vp[8] + rp[8];
+        double *vp = &sP[tid * 9];
+        double a[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) a[k] = 0.0;
+        for (int o = sStart[tid], o1 = sStart[tid + 1]; o < o1; ++o) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) a[k] += sV[o * 9 + k];
+        }
+        const double v00 = a[0], v01 = a[1], v02 = a[2], v11 = a[3], v12 = a[4], v22 = a[5];
+        const double g0 = a[6], g1 = a[7], g2 = a[8];
         gmax_loc = fmax(fabs(g0), fmax(fabs(g1), fabs(g2)));
         if (A.dbg_v) {
             double *dv = &A.dbg_v[(size_t)(pb + tid) * 6];
@@ -137,7 +146,7 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_lin(const BuildArgs A, double *__
         A.ck_gmax[ck] = fmax(fmax(sRed[4], sRed[5]), fmax(sRed[6], sRed[7]));
     }
     if (act && free_cam) {
-        const double *vp = &sP[0][lp * 9];
+        const double *vp = &sP[lp * 9];
         const double i00 = vp[0], i10 = vp[1], i11 = vp[2], i20 = vp[3], i21 = vp[4], i22 = vp[5];
         const double u0 = vp[6], u1 = vp[7], u2 = vp[8];
         double t[9];

@@ -37,10 +37,10 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
     auto tick = [&](const char *what) { if (tm_on) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[symbolic] %-22s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(t - tm_t0).count()); tm_t0 = t; } };
     s = Symbolic();
     s.deterministic = deterministic;
-    s.rows = rows && !deterministic;
+    s.rows = rows;
     // longest track on the chunk path (longer: heavy point).  The atomic-free build has no path for a camera without a
     // local slot, so there a point must fit the slots of one chunk.
-    const int max_chunk_track = deterministic ? CHUNK_CAMS_WIDE : CHUNK_OBS;
+    const int max_chunk_track = (deterministic && !rows) ? CHUNK_CAMS_WIDE : CHUNK_OBS;
     s.n_cams = n_cams;
     s.n_points = n_points;
     s.n_obs = n_obs;

@@ -107,14 +107,15 @@ void build_det_tables(const Symbolic &s, DetTables &t);
 // Phase A: ordering + chunking + this problem's own pair keys.  Returns 0 or a BA_ERR_* code.
 // deterministic: the structure for the atomic-free build -- no chunk holds more cameras than it has local slots
 // (CHUNK_CAMS_WIDE), and a point seen by more cameras than that is a heavy point.
-// rows: the "rows" mode of the Schur complement (Symbolic::rows; never together with deterministic).
+// rows: the "rows" mode of the Schur complement (Symbolic::rows).  Together with deterministic it is only usable when the
+// analysis finds no heavy point (their kernel adds with atomics): the caller checks n_heavy and analyses again without it.
 int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *cam_fixed,
                       const int32_t *obs_cam, const int32_t *obs_pt, Symbolic &s, const char **err, bool deterministic = false,
                       bool rows = false);
 // AUTO's rule for the rows mode, from a chunk-mode analysis: the chunk-local groups are mostly padding (fewer than three
 // real entries per group of eight on average) and the problem is large enough for it to matter.
 inline bool wants_rows_mode(const Symbolic &s) {
-    return !s.deterministic && !s.rows && s.n_pair_real >= 200000 && s.n_pair_real < 3 * s.n_groups;
+    return !s.rows && s.n_pair_real >= 200000 && s.n_pair_real < 3 * s.n_groups;
 }
 // Phase B: final pattern = own keys U extra keys; resolves chunk-local pairs to block slots.
 void finalize_pattern(Symbolic &s, const std::vector<int64_t> &extra_keys);
