@@ -8,19 +8,20 @@
 //   * row n is the right-hand side -g ("augmented" matrix): it goes through the panel solve and the trailing update like
 //     any other row, so when the factorisation is done it holds y = L^-1 (-g) -- the forward substitution costs nothing;
 //     rows behind it are padding with a unit diagonal;
-//   * per block column k, three launches:
-//       k_big_potrf  ONE workgroup: Cholesky of the 64 x 64 diagonal block in LDS, 16-column steps with the serial chain
-//                    on one wave (as k_bcr_factor), and the explicit inverse of its factor (so that the panel solve
-//                    below is a matrix product);
+//   * per block column k, two launches:
 //       k_big_trsm   one workgroup per 64 rows below: panel <- panel Linv^T on the fp64 matrix cores;
 //       k_big_syrk   one workgroup per 64 x 64 tile of the trailing lower triangle: tile -= P_I P_J^T, 64 MFMAs
-//                    (v_mfma_f64_16x16x4_f64) per wave, operand tiles staged through LDS;
-//   * backward substitution L^T x = y, one launch per block column from the last to the first: every workgroup forms
-//     x_k = Linv_k^T y_k (64 x 64, redundantly) and takes x_k out of one earlier block of y (a contiguous 64 x 64 block
-//     row of L).
-// The diagonal-block factorisation, the panel solve and the backward step of a block column are short serial launches
-// (19 + 10 + 14 us) during which most of the chip idles: 7 of the 18 ms of a solve at 10 k unknowns.
-// About 4 n / 64 launches, queued without host synchronisation; a non-positive pivot sets
+//                    (v_mfma_f64_16x16x4_f64) per wave, operand tiles staged through LDS; the workgroup of tile (0, 0) -- the
+//                    diagonal block of column k + 1, complete with this update -- keeps it in LDS and goes on to FACTOR it
+//                    while the rest of the grid is still updating (big_potrf_block: Cholesky in 16-column steps with the
+//                    serial chain on one wave, as k_bcr_factor, and the explicit inverse of the factor, so that the panel
+//                    solve is a matrix product).  Only column 0 has a launch of its own for that (k_big_potrf).
+//   * backward substitution L^T x = y, four block columns per launch from the last to the first: every workgroup solves the
+//     group's columns itself (redundantly) and takes their x out of one earlier block of y.
+// Round 2 had three launches per block column (the diagonal factorisation alone on the chip for 19 us) and one backward
+// launch per column whose matrix-vector products waited for their loads one row at a time: 18.6 ms per solve at 10 326
+// unknowns; now 15.0 (tools/ab_big.sh, tools/trace_big_dense.sh).
+// About 2.3 n / 64 launches, queued without host synchronisation; a non-positive pivot sets
 // *info (the LM step is then void and repeated with PCG, as for the other direct solvers).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -30,6 +31,9 @@
 
 #define BA_DENSE_BIG_MAX 12288   // unknowns: 2048 free cameras; the matrix takes 1.2 GB
 #define BA_BIG_NB 64
+#ifndef BA_BIG_FUSE
+#define BA_BIG_FUSE 1   // the diagonal factorisation of column k + 1 inside column k's trailing update (k_big_syrk)
+#endif
 
 namespace ba {
 
@@ -72,20 +76,14 @@ __global__ void k_big_init(int n, int M, const double *__restrict__ g, double *_
 // k index of an MFMA lane is free to mean), so nothing is staged in between.
 // (History: the block in LDS with three barriers per column, 87 us per block; one wave with a row of 64 per lane in
 // registers, 54 us -- a third of the whole solve at 10 k unknowns; this version: see DESIGN.md.)
-__global__ __launch_bounds__(256) void k_big_potrf(int k0, int M, double *__restrict__ A, double *__restrict__ Linv,
-                                                   int *__restrict__ info) {
+// (the factorisation proper: the 64 x 64 block is in sD; called by every thread of a 256-thread workgroup)
+__device__ __forceinline__ void big_potrf_block(double *__restrict__ sD, double *__restrict__ sLinv, int k0, int M,
+                                                double *__restrict__ A, double *__restrict__ Linv, int *__restrict__ info) {
     constexpr int NB = BA_BIG_NB, NT = NB / 16, LDD = NB + 1;
-    __shared__ double sD[NB * LDD];
-    __shared__ double sLinv[NT * 272];                  // diagonal tiles of the inverse, 16 x 17 each
-    __shared__ double sXo[(NT * (NT - 1) / 2) * 272];   // tiles below the diagonal: (i, j) at i (i - 1) / 2 + j
-    auto xtile = [&](int i, int j) -> double * { return i == j ? sLinv + i * 272 : sXo + (i * (i - 1) / 2 + j) * 272; };
+    // X tiles: the diagonal ones in sLinv (16 x 17 each); tile (i, j), i > j, in the never-used upper tile (j, i) of sD
+    auto xel = [&](int i, int j, int a, int b) -> double & { return i == j ? sLinv[i * 272 + a * 17 + b] : sD[(16 * j + a) * LDD + 16 * i + b]; };
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int r = e / NB, c = e - r * NB;
-        sD[r * LDD + c] = A[(size_t)(k0 + r) * M + k0 + c];   // (entries right of the diagonal are never used)
-    }
-    __syncthreads();
     int bad = 0;
     auto panel_tile = [&](int i, int s) {   // (i, s) <- (i, s) Linv_s^T
         mfma_d4 w = mfma_d4{0.0, 0.0, 0.0, 0.0};
@@ -155,23 +153,37 @@ __global__ __launch_bounds__(256) void k_big_potrf(int k0, int M, double *__rest
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     w = __builtin_amdgcn_mfma_f64_16x16x4f64(sD[(16 * i + l15) * LDD + 16 * k + 4 * q + l4],
-                                                             xtile(k, j)[(4 * q + l4) * 17 + l15], w, 0, 0, 0);
+                                                             xel(k, j, 4 * q + l4, l15), w, 0, 0, 0);
             }
             mfma_d4 x = mfma_d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 x = __builtin_amdgcn_mfma_f64_16x16x4f64(-sLinv[i * 272 + l15 * 17 + 4 * q + l4], w[q], x, 0, 0, 0);
 #pragma unroll
-            for (int v = 0; v < 4; ++v) xtile(i, j)[(l4 + 4 * v) * 17 + l15] = x[v];
+            for (int v = 0; v < 4; ++v) xel(i, j, l4 + 4 * v, l15) = x[v];
         }
         __syncthreads();
     }
     for (int e = tid; e < NB * NB; e += 256) {
         const int r = e / NB, c = e - r * NB;
         if (c <= r) A[(size_t)(k0 + r) * M + k0 + c] = sD[r * LDD + c];
-        Linv[e] = c <= r ? xtile(r >> 4, c >> 4)[(r & 15) * 17 + (c & 15)] : 0.0;
+        Linv[e] = c <= r ? xel(r >> 4, c >> 4, r & 15, c & 15) : 0.0;
     }
     if (tid == 0 && bad) atomicCAS(info, 0, k0 + 1);
+}
+
+__global__ __launch_bounds__(256) void k_big_potrf(int k0, int M, double *__restrict__ A, double *__restrict__ Linv,
+                                                   int *__restrict__ info) {
+    constexpr int NB = BA_BIG_NB, NT = NB / 16, LDD = NB + 1;
+    __shared__ double sD[NB * LDD];
+    __shared__ double sLinv[NT * 272];                  // diagonal tiles of the inverse, 16 x 17 each
+    const int tid = threadIdx.x;
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int r = e / NB, c = e - r * NB;
+        sD[r * LDD + c] = A[(size_t)(k0 + r) * M + k0 + c];   // (entries right of the diagonal are never used)
+    }
+    __syncthreads();
+    big_potrf_block(sD, sLinv, k0, M, A, Linv, info);
 }
 
 // panel rows r0 .. r0+63 (r0 = k0 + 64 (1 + blockIdx.x)): P <- P Linv^T.  256 threads = 4 waves of 16 rows.
@@ -213,10 +225,16 @@ __global__ __launch_bounds__(256) void k_big_trsm(int k0, int M, double *__restr
 // operand tiles are staged through LDS in two halves of K (coalesced 256-byte row pieces): read straight from L2, one
 // MFMA operand load touches 16 cache lines for 512 useful bytes and the vector cache becomes the limit (the first
 // version ran at 16 % of the MFMA rate).  34 KB of LDS per workgroup: four workgroups per CU.
-__global__ __launch_bounds__(256) void k_big_syrk(int k0, int M, double *__restrict__ A) {
-    constexpr int NB = BA_BIG_NB, KH = 32, LD = KH + 1;
-    __shared__ double sA[NB * LD];
-    __shared__ double sB[NB * LD];
+// FUSE: the workgroup of tile (0, 0) -- the diagonal block of the NEXT block column, complete once this update is applied --
+// goes on to factor it (big_potrf_block) while the rest of the grid is still updating: no launch of its own for the
+// diagonal factorisation, and not 19 us per block column with one workgroup on the chip.  (Its LDS -- the block,
+// the diagonal tiles of the inverse -- lies over and behind the operand buffers: 42.5 KB per workgroup instead of 34.)
+template <bool FUSE>
+__global__ __launch_bounds__(256) void k_big_syrk(int k0, int M, double *__restrict__ A, double *__restrict__ Linv_next, int *__restrict__ info) {
+    constexpr int NB = BA_BIG_NB, KH = 32, LD = KH + 1, NT = NB / 16, LDD = NB + 1;
+    __shared__ double sAB[2 * NB * LD > NB * LDD ? 2 * NB * LD : NB * LDD];
+    __shared__ double sLinv[FUSE ? NT * 272 : 1];
+    double *sA = sAB, *sB = sAB + NB * LD;
     // (I, J) from the linear index t = I (I + 1) / 2 + J
     const int t = blockIdx.x;
     int I = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
@@ -247,6 +265,23 @@ __global__ __launch_bounds__(256) void k_big_syrk(int k0, int M, double *__restr
             for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sB[(q * 16 + l15) * LD + kc + l4], acc[q], 0, 0, 0);
         }
     }
+    if (FUSE && t == 0) {
+        // the updated diagonal block of the next column: into LDS (over the operand buffers) instead of back to HBM,
+        // factored in place; big_potrf_block stores the factor and its inverse
+        __syncthreads();   // everybody is done with the operands
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const double *cp = &A[(size_t)(rI + wv * 16 + l4 + 4 * v) * M + rJ + l15];
+            double old[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) old[q] = cp[q * 16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sAB[(wv * 16 + l4 + 4 * v) * LDD + q * 16 + l15] = old[q] - acc[q][v];
+        }
+        __syncthreads();
+        big_potrf_block(sAB, sLinv, rI, M, A, Linv_next, info);
+        return;
+    }
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
         double *cp = &A[(size_t)(rI + wv * 16 + l4 + 4 * v) * M + rJ + l15];
@@ -258,39 +293,79 @@ __global__ __launch_bounds__(256) void k_big_syrk(int k0, int M, double *__restr
     }
 }
 
-// backward substitution, block column kb (k0 = 64 kb), launched for kb = last .. 0 with grid kb + 1:
-// every workgroup forms x_k = Linv_k^T y_k; workgroup j < kb takes it out of y_j (y lives in row n of A), workgroup kb
-// stores x_k.  Only indices < n count (the right-hand-side row and the padding carry no unknowns).
-__global__ __launch_bounds__(256) void k_big_back(int kb, int n, int M, double *__restrict__ A, const double *__restrict__ Linv_all,
+// backward substitution, BA_BIG_BACK_G block columns per launch (c_hi down to c_lo), launched from the last group to the
+// first with grid c_lo + 1: EVERY workgroup solves the group's columns itself (redundantly, same arithmetic, same bits):
+//   for c = c_hi .. c_lo:  x_c = Linv_c^T (y_c - sum over the group's later columns c' of L[c', c]^T x_c')
+// -- ten 64 x 64 matrix-vector products out of L2 for a group of four -- then workgroup j < c_lo takes the group's x out of
+// y_j (y lives in row n of A), and workgroup c_lo stores x.  One launch per block column (the first version) spent 14 us
+// per column with most of the chip idle: 2.3 of 16 ms at 10 k unknowns.  Only indices < n count (the right-hand-side row
+// and the padding carry no unknowns).
+#ifndef BA_BIG_BACK_G
+#define BA_BIG_BACK_G 4
+#endif
+__global__ __launch_bounds__(256) void k_big_back(int c_hi, int n, int M, double *__restrict__ A, const double *__restrict__ Linv_all,
                                                   double *__restrict__ x) {
-    constexpr int NB = BA_BIG_NB;
-    __shared__ double sx[NB];
+    constexpr int NB = BA_BIG_NB, G = BA_BIG_BACK_G;
+    __shared__ double sx[G][NB];
+    __shared__ double sy[NB];
     __shared__ double sred[4][NB];
-    const int tid = threadIdx.x, k0 = kb * NB;
-    const double *Linv = Linv_all + (size_t)kb * NB * NB;
+    const int tid = threadIdx.x, col = tid & 63, part = tid >> 6;
+    const int c_lo = c_hi - G + 1 > 0 ? c_hi - G + 1 : 0, ng = c_hi - c_lo + 1;
     double *y = A + (size_t)n * M;
-    const int rmax = n - k0 < NB ? n - k0 : NB;   // unknowns in this block
-    {
-        // x_k[c] = sum_r Linv[r][c] y[r] (Linv is lower triangular: r >= c); thread (c, part) takes r = part mod 4
-        const int c = tid & 63, part = tid >> 6;
+    for (int gi = 0; gi < ng; ++gi) {
+        const int c = c_hi - gi, k0 = c * NB;
+        const int rmax = n - k0 < NB ? n - k0 : NB;   // unknowns in this block
+        // y_c less the columns of the group already solved
         double s = 0.0;
-        for (int r = part; r < rmax; r += 4) s += Linv[r * NB + c] * y[k0 + r];
-        sred[part][c] = s;
+        for (int gj = 0; gj < gi; ++gj) {
+            const int k1 = (c_hi - gj) * NB, rm1 = n - k1 < NB ? n - k1 : NB;
+            (void)rm1;   // (x beyond the unknowns is zero, the rows behind them are padding: every load is unconditional)
+            double v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = A[(size_t)(k1 + part * 16 + r) * M + k0 + col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += v[r] * sx[gj][part * 16 + r];
+        }
+        sred[part][col] = s;
         __syncthreads();
-        if (tid < NB) sx[tid] = tid < rmax ? (sred[0][tid] + sred[1][tid]) + (sred[2][tid] + sred[3][tid]) : 0.0;
+        if (tid < NB) sy[tid] = tid < rmax ? y[k0 + tid] - ((sred[0][tid] + sred[1][tid]) + (sred[2][tid] + sred[3][tid])) : 0.0;
+        __syncthreads();
+        // x_c[col] = sum_r Linv[r][col] y[r] (Linv is lower triangular: r >= col); thread (col, part) takes r = part mod 4
+        const double *Linv = Linv_all + (size_t)c * NB * NB;
+        s = 0.0;
+        {
+            double v[16];   // (y beyond the unknowns is zero)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = Linv[(part + 4 * r) * NB + col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += v[r] * sy[part + 4 * r];
+        }
+        sred[part][col] = s;
+        __syncthreads();
+        if (tid < NB) sx[gi][tid] = tid < rmax ? (sred[0][tid] + sred[1][tid]) + (sred[2][tid] + sred[3][tid]) : 0.0;
         __syncthreads();
     }
     const int j = blockIdx.x;
-    if (j == kb) {
-        if (tid < rmax) x[k0 + tid] = sx[tid];
+    if (j == c_lo) {
+        for (int gi = 0; gi < ng; ++gi) {
+            const int k0 = (c_hi - gi) * NB, rmax = n - k0 < NB ? n - k0 : NB;
+            if (tid < rmax) x[k0 + tid] = sx[gi][tid];
+        }
         return;
     }
-    // y_j[c] -= sum_r L[k0 + r][j0 + c] x_k[r]
-    const int c = tid & 63, part = tid >> 6, j0 = j * NB;
+    // y_j[col] -= sum over the group's columns c and rows r of L[64 c + r][64 j + col] x_c[r]
+    const int j0 = j * NB;
     double s = 0.0;
-    for (int r = part * 16; r < part * 16 + 16; ++r)
-        if (r < rmax) s += A[(size_t)(k0 + r) * M + j0 + c] * sx[r];
-    sred[part][c] = s;
+    for (int gi = 0; gi < ng; ++gi) {
+        const int k0 = (c_hi - gi) * NB, rmax = n - k0 < NB ? n - k0 : NB;
+        (void)rmax;
+        double v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = A[(size_t)(k0 + part * 16 + r) * M + j0 + col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += v[r] * sx[gi][part * 16 + r];
+    }
+    sred[part][col] = s;
     __syncthreads();
     if (tid < NB) y[j0 + tid] -= (sred[0][tid] + sred[1][tid]) + (sred[2][tid] + sred[3][tid]);
 }
@@ -312,17 +387,22 @@ inline hipError_t big_solve_launch(hipStream_t st, int n, int n_upper, const lon
     const int ne = n_upper * 36;
     hipLaunchKernelGGL(k_big_assemble, dim3((ne + 255) / 256), dim3(256), 0, st, n_upper, keys, S, M, A);
     hipLaunchKernelGGL(k_big_init, dim3((M + 255) / 256), dim3(256), 0, st, n, M, g, A);
-    for (int kb = 0; kb < nblk; ++kb) {
+    hipLaunchKernelGGL(k_big_potrf, dim3(1), dim3(256), 0, st, 0, M, A, Linv, info);
+    for (int kb = 0; kb + 1 < nblk; ++kb) {
+        // block column kb: panel solve, trailing update -- whose first workgroup also factors the diagonal block of column kb + 1
         const int k0 = kb * BA_BIG_NB, below = nblk - 1 - kb;
         double *li = Linv + (size_t)kb * BA_BIG_NB * BA_BIG_NB;
-        hipLaunchKernelGGL(k_big_potrf, dim3(1), dim3(256), 0, st, k0, M, A, li, info);
-        if (below > 0) {
-            hipLaunchKernelGGL(k_big_trsm, dim3(below), dim3(256), 0, st, k0, M, A, li);
-            hipLaunchKernelGGL(k_big_syrk, dim3(below * (below + 1) / 2), dim3(256), 0, st, k0, M, A);
+        hipLaunchKernelGGL(k_big_trsm, dim3(below), dim3(256), 0, st, k0, M, A, li);
+        if (BA_BIG_FUSE) hipLaunchKernelGGL((k_big_syrk<true>), dim3(below * (below + 1) / 2), dim3(256), 0, st, k0, M, A, li + BA_BIG_NB * BA_BIG_NB, info);
+        else {
+            hipLaunchKernelGGL((k_big_syrk<false>), dim3(below * (below + 1) / 2), dim3(256), 0, st, k0, M, A, (double *)nullptr, (int *)nullptr);
+            hipLaunchKernelGGL(k_big_potrf, dim3(1), dim3(256), 0, st, k0 + BA_BIG_NB, M, A, li + BA_BIG_NB * BA_BIG_NB, info);
         }
     }
-    for (int kb = (n - 1) / BA_BIG_NB; kb >= 0; --kb)
-        hipLaunchKernelGGL(k_big_back, dim3(kb + 1), dim3(256), 0, st, kb, n, M, A, Linv, x);
+    for (int c_hi = (n - 1) / BA_BIG_NB; c_hi >= 0; c_hi -= BA_BIG_BACK_G) {
+        const int c_lo = c_hi - BA_BIG_BACK_G + 1 > 0 ? c_hi - BA_BIG_BACK_G + 1 : 0;
+        hipLaunchKernelGGL(k_big_back, dim3(c_lo + 1), dim3(256), 0, st, c_hi, n, M, A, Linv, x);
+    }
     return hipGetLastError();
 }
 

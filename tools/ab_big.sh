@@ -1,0 +1,10 @@
+#!/bin/bash
+cd "$(dirname "$0")/.."
+cp structure_from_motion_amd/libba_hip.so /tmp/new.so
+for rep in 1 2; do
+  for which in old new; do
+    if [ $which = old ]; then cp structure_from_motion_amd/libba_old.so structure_from_motion_amd/libba_hip.so; else cp /tmp/new.so structure_from_motion_amd/libba_hip.so; fi
+    echo -n "$which: "; timeout -k 10 200 python tools/big_dense_time.py ladybug1723 | tail -1; echo -n "$which orbit: "; timeout -k 10 200 python tools/big_dense_time.py orbit1024 | tail -1
+  done
+done
+cp /tmp/new.so structure_from_motion_amd/libba_hip.so
