@@ -8,19 +8,22 @@
 //   * row n is the right-hand side -g ("augmented" matrix): it goes through the panel solve and the trailing update like
 //     any other row, so when the factorisation is done it holds y = L^-1 (-g) -- the forward substitution costs nothing;
 //     rows behind it are padding with a unit diagonal;
-//   * per block column k, two launches:
+//   * block columns are taken in GROUPS of two: inside a group the second column first receives the first one's update
+//     (k_big_syrk, col_only), each column's panel is solved (k_big_trsm), and the trailing matrix behind the group is
+//     updated by both panels in ONE pass (K = 128):
 //       k_big_trsm   one workgroup per 64 rows below: panel <- panel Linv^T on the fp64 matrix cores;
-//       k_big_syrk   one workgroup per 64 x 64 tile of the trailing lower triangle: tile -= P_I P_J^T, 64 MFMAs
-//                    (v_mfma_f64_16x16x4_f64) per wave, operand tiles staged through LDS; the workgroup of tile (0, 0) -- the
-//                    diagonal block of column k + 1, complete with this update -- keeps it in LDS and goes on to FACTOR it
-//                    while the rest of the grid is still updating (big_potrf_block: Cholesky in 16-column steps with the
-//                    serial chain on one wave, as k_bcr_factor, and the explicit inverse of the factor, so that the panel
-//                    solve is a matrix product).  Only column 0 has a launch of its own for that (k_big_potrf).
+//       k_big_syrk   one workgroup per 64 x 64 tile: tile -= P_I P_J^T, K / 4 MFMAs (v_mfma_f64_16x16x4_f64) per wave and
+//                    16 x 16 piece, operand tiles staged through LDS 32 columns of K at a time; the workgroup of tile (0, 0)
+//                    -- the diagonal block of the next column, complete with this update -- keeps it in LDS and goes on to
+//                    FACTOR it while the rest of the grid is still updating (big_potrf_block: Cholesky in 16-column steps
+//                    with the serial chain on one wave, as k_bcr_factor, and the explicit inverse of the factor, so that
+//                    the panel solve is a matrix product).  Only column 0 has a launch of its own for that (k_big_potrf).
 //   * backward substitution L^T x = y, four block columns per launch from the last to the first: every workgroup solves the
 //     group's columns itself (redundantly) and takes their x out of one earlier block of y.
-// Round 2 had three launches per block column (the diagonal factorisation alone on the chip for 19 us) and one backward
-// launch per column whose matrix-vector products waited for their loads one row at a time: 18.6 ms per solve at 10 326
-// unknowns; now 15.0 (tools/ab_big.sh, tools/trace_big_dense.sh).
+// Round 2 had three launches per block column (the diagonal factorisation alone on the chip for 19 us), one pass over the
+// trailing matrix per block column, and one backward launch per column whose matrix-vector products waited for their loads
+// one row at a time: 18.6 ms per LM step at 10 326 unknowns; round 3: 13.7 (tools/ab_big.sh, tools/trace_big_dense.sh;
+// groups of four columns: 13.5 there, but slower at 6 k unknowns).
 // About 2.3 n / 64 launches, queued without host synchronisation; a non-positive pivot sets
 // *info (the LM step is then void and repeated with PCG, as for the other direct solvers).
 #pragma once
@@ -31,8 +34,8 @@
 
 #define BA_DENSE_BIG_MAX 12288   // unknowns: 2048 free cameras; the matrix takes 1.2 GB
 #define BA_BIG_NB 64
-#ifndef BA_BIG_FUSE
-#define BA_BIG_FUSE 1   // the diagonal factorisation of column k + 1 inside column k's trailing update (k_big_syrk)
+#ifndef BA_BIG_GROUP
+#define BA_BIG_GROUP 2   // block columns per pass over the trailing matrix
 #endif
 
 namespace ba {
@@ -230,30 +233,37 @@ __global__ __launch_bounds__(256) void k_big_trsm(int k0, int M, double *__restr
 // diagonal factorisation, and not 19 us per block column with one workgroup on the chip.  (Its LDS -- the block,
 // the diagonal tiles of the inverse -- lies over and behind the operand buffers: 42.5 KB per workgroup instead of 34.)
 template <bool FUSE>
-__global__ __launch_bounds__(256) void k_big_syrk(int k0, int M, double *__restrict__ A, double *__restrict__ Linv_next, int *__restrict__ info) {
+__global__ __launch_bounds__(256) void k_big_syrk(int kp, int K, int rb, int col_only, int M, double *__restrict__ A, double *__restrict__ Linv_next,
+                                                  int *__restrict__ info) {
+    // tiles (I, J), I >= J, of the lower triangle whose first row / column is rb:  C -= P_I P_J^T with the panels
+    // P = A[., kp .. kp + K) (K = 64: one block column; K = 128: two at once -- half the passes over the trailing matrix).
+    // col_only: only the tiles (I, 0) -- the block column that has to be complete before the second panel can be solved.
     constexpr int NB = BA_BIG_NB, KH = 32, LD = KH + 1, NT = NB / 16, LDD = NB + 1;
     __shared__ double sAB[2 * NB * LD > NB * LDD ? 2 * NB * LD : NB * LDD];
     __shared__ double sLinv[FUSE ? NT * 272 : 1];
     double *sA = sAB, *sB = sAB + NB * LD;
-    // (I, J) from the linear index t = I (I + 1) / 2 + J
     const int t = blockIdx.x;
-    int I = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-    while ((I + 1) * (I + 2) / 2 <= t) ++I;
-    while (I * (I + 1) / 2 > t) --I;
-    const int J = t - I * (I + 1) / 2;
+    int I, J;
+    if (col_only) {
+        I = t; J = 0;
+    } else {   // (I, J) from the linear index t = I (I + 1) / 2 + J
+        I = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while ((I + 1) * (I + 2) / 2 <= t) ++I;
+        while (I * (I + 1) / 2 > t) --I;
+        J = t - I * (I + 1) / 2;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
-    const int rI = k0 + NB * (1 + I), rJ = k0 + NB * (1 + J);
+    const int rI = rb + NB * I, rJ = rb + NB * J;
     mfma_d4 acc[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[q] = mfma_d4{0.0, 0.0, 0.0, 0.0};
     const int lr = tid >> 2, lc = (tid & 3) * 8;   // loader: row lr, eight consecutive k
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const double *ga = &A[(size_t)(rI + lr) * M + k0 + h * KH + lc], *gb = &A[(size_t)(rJ + lr) * M + k0 + h * KH + lc];
+    for (int h = 0; h < K / KH; ++h) {
+        const double *ga = &A[(size_t)(rI + lr) * M + kp + h * KH + lc], *gb = &A[(size_t)(rJ + lr) * M + kp + h * KH + lc];
         double va[8], vb[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) { va[k] = ga[k]; vb[k] = gb[k]; }
-        if (h) __syncthreads();   // everybody is done with the first half
+        if (h) __syncthreads();   // everybody is done with the previous piece of K
 #pragma unroll
         for (int k = 0; k < 8; ++k) { sA[lr * LD + lc + k] = va[k]; sB[lr * LD + lc + k] = vb[k]; }
         __syncthreads();
@@ -265,7 +275,7 @@ __global__ __launch_bounds__(256) void k_big_syrk(int k0, int M, double *__restr
             for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sB[(q * 16 + l15) * LD + kc + l4], acc[q], 0, 0, 0);
         }
     }
-    if (FUSE && t == 0) {
+    if (FUSE && I == 0 && J == 0) {
         // the updated diagonal block of the next column: into LDS (over the operand buffers) instead of back to HBM,
         // factored in place; big_potrf_block stores the factor and its inverse
         __syncthreads();   // everybody is done with the operands
@@ -388,16 +398,25 @@ inline hipError_t big_solve_launch(hipStream_t st, int n, int n_upper, const lon
     hipLaunchKernelGGL(k_big_assemble, dim3((ne + 255) / 256), dim3(256), 0, st, n_upper, keys, S, M, A);
     hipLaunchKernelGGL(k_big_init, dim3((M + 255) / 256), dim3(256), 0, st, n, M, g, A);
     hipLaunchKernelGGL(k_big_potrf, dim3(1), dim3(256), 0, st, 0, M, A, Linv, info);
-    for (int kb = 0; kb + 1 < nblk; ++kb) {
-        // block column kb: panel solve, trailing update -- whose first workgroup also factors the diagonal block of column kb + 1
-        const int k0 = kb * BA_BIG_NB, below = nblk - 1 - kb;
-        double *li = Linv + (size_t)kb * BA_BIG_NB * BA_BIG_NB;
-        hipLaunchKernelGGL(k_big_trsm, dim3(below), dim3(256), 0, st, k0, M, A, li);
-        if (BA_BIG_FUSE) hipLaunchKernelGGL((k_big_syrk<true>), dim3(below * (below + 1) / 2), dim3(256), 0, st, k0, M, A, li + BA_BIG_NB * BA_BIG_NB, info);
-        else {
-            hipLaunchKernelGGL((k_big_syrk<false>), dim3(below * (below + 1) / 2), dim3(256), 0, st, k0, M, A, (double *)nullptr, (int *)nullptr);
-            hipLaunchKernelGGL(k_big_potrf, dim3(1), dim3(256), 0, st, k0 + BA_BIG_NB, M, A, li + BA_BIG_NB * BA_BIG_NB, info);
+    constexpr int NB = BA_BIG_NB;
+    for (int kb = 0; kb < nblk;) {
+        // a GROUP of g block columns kb .. kb + g - 1 at a time: inside the group column c first receives the update of the
+        // group's earlier panels (col_only, K = 64 c; its tile (0, 0) is column c's diagonal block -- factored by that
+        // workgroup), then its panel is solved; the trailing matrix behind the group is then updated by all g panels in ONE
+        // pass (K = 64 g): the pass over the trailing matrix, which is what the factorisation streams from HBM, happens once
+        // per group instead of once per block column.
+        const int g = nblk - kb < BA_BIG_GROUP ? nblk - kb : BA_BIG_GROUP, kp = kb * NB;
+        for (int c = 0; c < g; ++c) {
+            const int col = kb + c, below = nblk - 1 - col;
+            double *li = Linv + (size_t)col * NB * NB;
+            if (c > 0) hipLaunchKernelGGL((k_big_syrk<true>), dim3(below + 1), dim3(256), 0, st, kp, c * NB, col * NB, 1, M, A, li, info);
+            if (below > 0) hipLaunchKernelGGL(k_big_trsm, dim3(below), dim3(256), 0, st, col * NB, M, A, li);
         }
+        const int T = nblk - (kb + g);
+        if (T > 0)
+            hipLaunchKernelGGL((k_big_syrk<true>), dim3(T * (T + 1) / 2), dim3(256), 0, st, kp, g * NB, (kb + g) * NB, 0, M, A,
+                               Linv + (size_t)(kb + g) * NB * NB, info);
+        kb += g;
     }
     for (int c_hi = (n - 1) / BA_BIG_NB; c_hi >= 0; c_hi -= BA_BIG_BACK_G) {
         const int c_lo = c_hi - BA_BIG_BACK_G + 1 > 0 ? c_hi - BA_BIG_BACK_G + 1 : 0;
