@@ -492,32 +492,49 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
 
     BA_STAMP(9);
     // ---- phase 4: one flush per chunk (fp64 atomics to HBM) ------------------------------------------
-    for (int i = tid; i < ntile * 33; i += CHUNK_OBS) {
-        const int l = i / 33, k = i - l * 33;
-        const size_t f = (size_t)sCam[l];
-        const double v = sC[i];
-        if (k < 21) atomicAdd(&A.U[f * 21 + k], v);
-        else if (k < 27) atomicAdd(&A.gc[f * 6 + (k - 21)], v);
-        else atomicAdd(&A.gred[f * 6 + (k - 27)], v);
+    // Element i = tid + 256 t of the flat lists (camera tile l = i / 33, k = i % 33; pair l = i / 36, k = i % 36): l and k are
+    // stepped, not divided, and TWO elements are in flight per trip -- their index words, then their partial blocks, are
+    // requested together (one element per trip with a division was a chain of three dependent LDS round trips and some fifty
+    // instructions, fifteen times per lane: a sixth of the kernel).
+    {
+        const int n_items = ntile * 33;
+        int l = tid / 33, k = tid - l * 33;   // 256 = 7 * 33 + 25
+        for (int i = tid; i < n_items; i += CHUNK_OBS) {
+            const size_t f = (size_t)sCam[l];
+            const double v = sC[i];
+            double *dst = k < 21 ? &A.U[f * 21 + k] : (k < 27 ? &A.gc[f * 6 + (k - 21)] : &A.gred[f * 6 + (k - 27)]);
+            atomicAdd(dst, v);
+            l += 7; k += 25;
+            if (k >= 33) { k -= 33; l += 1; }
+        }
     }
     {
         // Schur blocks: element k of pair l = sum over the pair's groups of the parked partial blocks.  Only pairs
         // with a group in the first round are parked; their offsets and block slots were staged in phase 0.
         const int np1 = npair < CHUNK_OBS / 2 ? npair : CHUNK_OBS / 2;
-        for (int i = tid; i < np1 * 36; i += CHUNK_OBS) {
-            const int l = i / 36, k = i - l * 36;
-            const int g0 = sPg[l];
-            int g1 = sPg[l + 1];
-            if (g1 > CHUNK_OBS / 2) g1 = CHUNK_OBS / 2;  // later rounds went to HBM directly
-            double v = 0.0;
-            for (int g = g0; g < g1; g += 4) {  // four partial blocks per trip, loads issued together
-                double x[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) x[u] = sT[(g + u < g1 ? g + u : g0) * 36 + k];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) v += (g + u < g1) ? x[u] : 0.0;
-            }
-            if (g1 > g0) atomicAdd(&A.S[(size_t)sSlot[l] * 36 + k], v);
+        const int n_items = np1 * 36;
+        int l = tid / 36, k = tid - l * 36;   // 256 = 7 * 36 + 4; the second element of a trip is 256 further
+        for (int i = tid; i < n_items; i += 2 * CHUNK_OBS) {
+            int l2 = l + 7, k2 = k + 4;
+            if (k2 >= 36) { k2 -= 36; l2 += 1; }
+            const bool on2 = i + CHUNK_OBS < n_items;
+            if (!on2) { l2 = l; k2 = k; }
+            const int a0 = sPg[l], b0 = sPg[l2], slot_a = sSlot[l], slot_b = sSlot[l2];
+            int a1 = sPg[l + 1], b1 = sPg[l2 + 1];
+            if (a1 > CHUNK_OBS / 2) a1 = CHUNK_OBS / 2;  // later rounds went to HBM directly
+            if (b1 > CHUNK_OBS / 2) b1 = CHUNK_OBS / 2;
+            // the first two groups of each element unconditionally (a pair seldom has more), the rest in a loop
+            // (a pair whose groups all lie in later rounds has a0 >= a1: nothing is added, the reads stay inside the buffer)
+            const int a0c = a0 < a1 ? a0 : 0, b0c = b0 < b1 ? b0 : 0;
+            const double xa0 = sT[a0c * 36 + k], xa1 = sT[(a0 + 1 < a1 ? a0 + 1 : a0c) * 36 + k];
+            const double xb0 = sT[b0c * 36 + k2], xb1 = sT[(b0 + 1 < b1 ? b0 + 1 : b0c) * 36 + k2];
+            double va = xa0 + (a0 + 1 < a1 ? xa1 : 0.0), vb = xb0 + (b0 + 1 < b1 ? xb1 : 0.0);
+            for (int g = a0 + 2; g < a1; ++g) va += sT[g * 36 + k];
+            for (int g = b0 + 2; g < b1; ++g) vb += sT[g * 36 + k2];
+            if (a1 > a0) atomicAdd(&A.S[(size_t)slot_a * 36 + k], va);
+            if (on2 && b1 > b0) atomicAdd(&A.S[(size_t)slot_b * 36 + k2], vb);
+            l += 14; k += 8;   // 512 = 14 * 36 + 8
+            if (k >= 36) { k -= 36; l += 1; }
         }
     }
     BA_STAMP(10);
