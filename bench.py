@@ -110,11 +110,13 @@ def other_configs(_capi, synthetic):
         from structure_from_motion_amd.session import BASession
         ids, image_data, pts = synthetic.to_image_data(p)
         import gc
-        gc.collect()                   # the containers just built are the bench's own garbage pressure, not the call's
         session = BASession()          # ONE session for all repetitions: its first call is the cold one, the rest are warm
         for name, fn in (("wall_ms_final_ba_dict_api", lambda d: BA.final_ba(d, pts, ids, verbose=False)),
                          ("wall_ms_final_ba_session", lambda d: session.final_ba(d, pts, ids, verbose=False))):
             times = []
+            _pts = _d = None
+            gc.collect()               # (the containers built above and the previous loop's results are the bench's own
+                                       # garbage: a full collection over 100 k objects inside a timed call costs 60 ms)
             for _rep in range(4):      # (every call starts from the driver's containers again)
                 d = dict(image_data)
                 t0 = time.perf_counter()

@@ -34,10 +34,19 @@ def problem_of(g):
                 obs_cam=g["obs_cam"], obs_pt=g["obs_pt"], obs_xy=g["obs_xy"])
 
 
+try:   # PyTorch-ROCm brings its own HIP runtime: loaded (and asked) BEFORE the library initialises the one it links, both
+    import torch   # serve the process; the other way round torch.cuda.is_available() turns False
+    _TORCH_SEES_GPU = torch.cuda.is_available()
+except Exception:
+    _TORCH_SEES_GPU = False
+
+
 def _gpu_available():
-    try:
-        import torch
-        return torch.cuda.is_available()
+    if _TORCH_SEES_GPU:
+        return True
+    try:   # the library's own answer
+        from structure_from_motion_amd import _capi
+        return bool(_capi.warm_up())
     except Exception:
         return False
 
