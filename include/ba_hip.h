@@ -86,7 +86,10 @@ typedef struct BaOptions {
                               a (nearly) full pattern up to 2048 free cameras: blocked dense Cholesky or block-Jacobi PCG,
                               whichever the first two steps time as faster; block-Jacobi PCG otherwise.  BANDED_CHOLESKY (chains, at most 16 apart): on request, and under AUTO only
                               for a chain that the cyclic reduction cannot plan (fewer than two blocks) */
-    int32_t verbose;       /* 0 silent, 1 summary, 2 per-iteration table (<- verbose, :219) */
+    int32_t verbose;       /* 0 silent; 1 one summary line; 2 (<- verbose=2, :219) scipy's own progress table and closing lines, character
+                              for character (scipy/optimize/_lsq/common.py print_header_nonlinear / print_iteration_nonlinear: the
+                              starting point and every accepted step; then the termination message and "Function evaluations ...");
+                              3 the engine's table instead: every trial step, damping, PCG iterations, solver choices */
     int32_t device;        /* HIP device ordinal; -1 = current device */
     int32_t deterministic; /* 1: no floating-point sum whose order depends on timing (no fp64 atomics in LDS or HBM: owner-lane
                               gathers, one slab row per partial result, fixed-order segmented sums; csrc/ba_det.h) -- the

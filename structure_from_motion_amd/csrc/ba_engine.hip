@@ -963,7 +963,7 @@ int do_step(BaHandle *h) {
             // (a PCG that ran into its iteration cap did not solve the system: never the choice)
             h->auto_use_pcg = pcg_it < max_it && h->auto_ms_pcg > 0.f && h->auto_ms_direct > 0.f && h->auto_ms_pcg < h->auto_ms_direct;
             h->auto_phase = 2;
-            if (h->opt.verbose >= 2)
+            if (h->opt.verbose >= 3)
                 printf("[ba_hip] AUTO on a full pattern: blocked dense Cholesky %.2f ms, block-Jacobi PCG %.2f ms (%d iterations) -> %s\n",
                        h->auto_ms_direct, h->auto_ms_pcg, pcg_it, h->auto_use_pcg ? "PCG" : "dense");
         } else if (auto_pick && h->auto_phase == 2 && h->auto_use_pcg && 2 * pcg_it > 3 * h->auto_pcg_iters + 20) {
@@ -1688,10 +1688,38 @@ int ba_run(BaHandle *h, int32_t max_steps, BaSummary *out) {
         fill_summary(h, out, BA_ERR_NUMERIC, now_ms() - t0);
         return fail(BA_ERR_NUMERIC, "non-finite initial cost");
     }
+    // verbose = 2 is what the reference passes (least_squares(verbose=2), BundleAdjustment.py:219): scipy's own table --
+    // print_header_nonlinear / print_iteration_nonlinear of scipy/optimize/_lsq/common.py, one row for the starting point
+    // and one per ACCEPTED step (scipy's iterations; nfev counts every trial step) -- and its two closing lines.
+    // verbose >= 3: the engine's table (every trial step, damping, PCG iterations) and collective traces.
     const int verbose = h->opt.verbose;
-    if (verbose >= 2)
+    auto centred = [](char *dst, const char *fmt, double v) {   // Python's '{:^15...}': the odd blank goes to the right
+        char num[32];
+        const int n = snprintf(num, sizeof num, fmt, v);
+        const int left = n < 15 ? (15 - n) / 2 : 0;
+        memset(dst, ' ', 15);
+        memcpy(dst + left, num, (size_t)(n < 15 - left ? n : 15 - left));
+        dst[15] = 0;
+    };
+    int scipy_iter = 0;
+    auto scipy_row = [&](int nfev, double cost, bool first, double reduction, double step_norm, double optimality) {
+        char c0[16], c1[16], c2[16], c3[16], c4[16], c5[16];
+        centred(c0, "%.0f", (double)scipy_iter);
+        centred(c1, "%.0f", (double)nfev);
+        centred(c2, "%.4e", cost);
+        if (first) { memset(c3, ' ', 15); c3[15] = 0; memset(c4, ' ', 15); c4[15] = 0; }
+        else { centred(c3, "%.2e", reduction); centred(c4, "%.2e", step_norm); }
+        centred(c5, "%.2e", optimality);
+        printf("%s%s%s%s%s%s\n", c0, c1, c2, c3, c4, c5);
+        ++scipy_iter;
+    };
+    if (verbose == 2) {
+        printf("   Iteration     Total nfev        Cost      Cost reduction    Step norm     Optimality   \n");
+        scipy_row(1, h->hstate.F, true, 0.0, 0.0, h->hstate.gmax);
+    } else if (verbose >= 3) {
         printf("   Iteration     Total nfev        Cost      Cost reduction    Step norm     Optimality      lambda   pcg\n"
                "%12d %12d %16.4e %46.2e\n", 0, 1, h->hstate.F, h->hstate.gmax);
+    }
     int status = 0;
     // (sharded solve: the point count is this rank's, and a rank that left the loop alone would leave its peers in a
     // collective; there gmax -- all-reduced -- ends an empty problem on every rank at once)
@@ -1713,7 +1741,11 @@ int ba_run(BaHandle *h, int32_t max_steps, BaSummary *out) {
             fresh = true;   // (nothing was built since the state was read)
             break;
         }
-        if (verbose >= 2)
+        // (scipy's row shows the gradient AT the new iterate: printed once the build that follows has been read back)
+        const bool row = verbose == 2 && s.accept;
+        const int row_nfev = s.iter + 1;
+        const double row_dF = s.dF, row_step = s.step_norm;
+        if (verbose >= 3)
             printf("%12d %12d %16.4e %16.2e %14.2e %14.2e %11.1e %5d %s\n", s.iter, s.iter + 1, s.F, s.accept ? s.dF : 0.0,
                    s.step_norm, s.gmax, s.lambda, h->total_pcg - pcg_before, s.accept ? "" : "(rejected)");
         if (s.terminate) {
@@ -1722,10 +1754,17 @@ int ba_run(BaHandle *h, int32_t max_steps, BaSummary *out) {
             if (s.accept && (e = do_build(h, false))) return e;
             if (s.accept && (e = read_state(h))) return e;
             fresh = true;
+            if (row) scipy_row(row_nfev, h->hstate.F, false, row_dF, row_step, h->hstate.gmax);
             break;
         }
         if ((e = do_build(h, false))) return e;  // new linearisation (accepted) or new damping (rejected)
         fresh = false;
+        if (row) {   // one more read-back per accepted step, in this mode only; the loop's own state is left as it was
+            const LmState keep = h->hstate;
+            if ((e = read_state(h))) return e;
+            scipy_row(row_nfev, h->hstate.F, false, row_dF, row_step, h->hstate.gmax);
+            h->hstate = keep;
+        }
     }
     if (!fresh && (e = read_state(h))) return e;
     fill_summary(h, out, status, now_ms() - t0);
@@ -1734,7 +1773,15 @@ int ba_run(BaHandle *h, int32_t max_steps, BaSummary *out) {
         if ((e = residual_sum(h, &c, &rs))) return e;
         out->residual_sum = rs;
     }
-    if (verbose >= 1)
+    if (verbose == 2) {
+        // least_squares' closing lines (scipy/optimize/_lsq/least_squares.py: TERMINATION_MESSAGES, then the summary)
+        static const char *const msg[5] = {"The maximum number of function evaluations is exceeded.", "`gtol` termination condition is satisfied.",
+                                           "`ftol` termination condition is satisfied.", "`xtol` termination condition is satisfied.",
+                                           "Both `ftol` and `xtol` termination conditions are satisfied."};
+        printf("%s\nFunction evaluations %d, initial cost %.4e, final cost %.4e, first-order optimality %.2e.\n",
+               msg[status >= 0 && status <= 4 ? status : 0], h->hstate.iter + 1, h->initial_cost, h->hstate.F, h->hstate.gmax);
+    }
+    if (verbose == 1 || verbose >= 3)
         printf("[ba_hip] status %d after %d steps (%d accepted, %d PCG iterations): cost %.6e -> %.6e, |g|inf %.2e\n", status,
                h->hstate.iter, h->hstate.n_accept, h->total_pcg, h->initial_cost, h->hstate.F, h->hstate.gmax);
     return BA_OK;

@@ -325,3 +325,40 @@ def test_opt_in_point_culling(gpu):
     assert sum(r != -1 for c in ids for r in image_data[c][3]) < before
     pts2, d2, ok = sess.final_ba(image_data, pts, ids, verbose=False)
     assert ok is True and pts2[victim][:3] == pts[victim][:3]             # unobserved point passes through
+
+
+def test_verbose_2_prints_scipys_table(gpu, capfd):
+    """The reference runs least_squares(verbose=2) (BundleAdjustment.py:219): scipy's progress table and closing lines.  The
+    engine prints the same lines -- checked against scipy's own formatting functions: header, one row for the start and one per
+    accepted step (centred 15-character columns), the termination message of the status and the summary line."""
+    import contextlib
+    import io
+    from scipy.optimize._lsq import common
+    from scipy.optimize._lsq.least_squares import TERMINATION_MESSAGES
+    from structure_from_motion_amd import _capi, synthetic
+    p = synthetic.make_street(6, 40, 160, seed=2)
+    arr = _capi.Arrays.from_dict(p)
+    capfd.readouterr()
+    s = _capi.solve(arr, loss="huber", f_scale=1.0, max_iter=30, verbose=2)
+    lines = [ln for ln in capfd.readouterr().out.split("\n") if ln.strip()]
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        common.print_header_nonlinear()
+    assert lines[0] == buf.getvalue().rstrip("\n")
+    rows = lines[1:-2]
+    assert len(rows) == s["accepted"] + 1
+    for k, row in enumerate(rows):
+        assert len(row) == 90
+        f = row.split()
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            if k == 0:
+                common.print_iteration_nonlinear(int(f[0]), int(f[1]), float(f[2]), None, None, float(f[3]))
+            else:
+                common.print_iteration_nonlinear(int(f[0]), int(f[1]), float(f[2]), float(f[3]), float(f[4]), float(f[5]))
+        assert row == buf.getvalue().rstrip("\n") and int(f[0]) == k
+    assert abs(float(rows[0].split()[2]) - s["initial_cost"]) <= 1e-4 * s["initial_cost"]
+    assert abs(float(rows[-1].split()[2]) - s["final_cost"]) <= 1e-4 * s["final_cost"]
+    assert lines[-2] == TERMINATION_MESSAGES[s["status"]]
+    assert lines[-1] == "Function evaluations {}, initial cost {:.4e}, final cost {:.4e}, first-order optimality {:.2e}.".format(
+        s["iterations"] + 1, s["initial_cost"], s["final_cost"], s["grad_inf"])
