@@ -214,13 +214,14 @@ def other_configs(_capi, synthetic):
     # block-Jacobi PCG forced beside it
     p = synthetic.make_config("ring1778_revisit")
     rev = {"cameras": len(p["cam_pose"]), "observations": len(p["obs_cam"]),
-           "solver": "auto = CG preconditioned by the cyclic reduction of the in-band part; pcg_tol_1e-8 forces block-Jacobi PCG"}
-    for tag, kw in (("auto_bcr_preconditioned_cg", {}), ("pcg_tol_1e-8", dict(linear_solver="pcg", pcg_tol=1e-8))):
+           "solver": "auto = CG preconditioned by the cyclic reduction of the in-band part, default tolerance (adaptive forcing "
+                     "term, BaOptions.pcg_tol = 0); auto_tol_1e-8: the same at a fixed 1e-8; pcg_tol_1e-8 forces block-Jacobi PCG"}
+    for tag, kw in (("auto_bcr_preconditioned_cg", {}), ("auto_tol_1e-8", dict(pcg_tol=1e-8)), ("pcg_tol_1e-8", dict(linear_solver="pcg", pcg_tol=1e-8))):
         with _capi.Handle(_capi.Arrays.from_dict(p), loss="huber", f_scale=1.0, max_iter=300, **kw) as h:
             h.run(1)
             h.synchronize()
             t0 = time.perf_counter()
-            s = h.run(10)
+            s = h.run(20)
             h.synchronize()
             dt = time.perf_counter() - t0
         steps = max(s["iterations"] - 1, 1)
@@ -235,8 +236,9 @@ def other_configs(_capi, synthetic):
     p = synthetic.make_config("orbit1024")
     n_unk = 6 * int((np.asarray(p["cam_fixed"]) == 0).sum())
     orbit = {"cameras": len(p["cam_pose"]), "observations": len(p["obs_cam"]), "unknowns": n_unk,
-             "solver": "auto = blocked dense Cholesky or block-Jacobi PCG, whichever the handle times as faster (full block pattern); pcg_tol_1e-8 forces block-Jacobi PCG"}
-    for tag, kw in (("auto_dense_cholesky", {}), ("pcg_tol_1e-8", dict(linear_solver="pcg", pcg_tol=1e-8))):
+             "solver": "auto = blocked dense Cholesky or block-Jacobi PCG at the default (adaptive) tolerance, whichever the handle times as "
+                       "faster (full block pattern); dense_cholesky forces the blocked dense solver; pcg_tol_1e-8 forces block-Jacobi PCG at a fixed 1e-8"}
+    for tag, kw in (("auto", {}), ("auto_dense_cholesky", dict(linear_solver="dense_cholesky")), ("pcg_tol_1e-8", dict(linear_solver="pcg", pcg_tol=1e-8))):
         with _capi.Handle(_capi.Arrays.from_dict(p), loss="huber", f_scale=1.0, max_iter=300, **kw) as h:
             if "build_ms" not in orbit:
                 # (AUTO's build pass on this shape is the rows mode, csrc/ba_rows.h; the chunk kernel is timed beside it below)
@@ -244,16 +246,16 @@ def other_configs(_capi, synthetic):
                 orbit["build_ms"], orbit["build_kernels_ms"] = h.build_bench(1e-4, warmup=0, reps=10)
                 orbit["build_obs_per_s"] = len(p["obs_cam"]) / orbit["build_ms"] * 1e3
                 orbit["build_mode"] = "rows" if _capi.analyze(h.arr)["auto_rows_mode"] else "chunks"
-            h.run(1)
+            h.run(3 if tag == "auto" else 1)   # (AUTO times both solvers on its first steps, then keeps the faster one)
             h.synchronize()
             t0 = time.perf_counter()
-            s = h.run(6)
+            s = h.run(8)
             h.synchronize()
             dt = time.perf_counter() - t0
-        steps = max(s["iterations"] - 1, 1)
+        steps = max(s["iterations"] - (3 if tag == "auto" else 1), 1)
         orbit[tag] = {"lm_steps": steps, "lm_iters_per_sec": steps / dt, "lm_pcg_iterations": s["pcg_iterations"],
                       "cost": [s["initial_cost"], s["final_cost"]]}
-        if not kw:
+        if tag == "auto_dense_cholesky":
             solve_s = dt / steps - orbit["build_ms"] * 1e-3
             orbit[tag]["solve_ms_upper_bound"] = solve_s * 1e3
             orbit[tag]["fp64_mfma_tflops_lower_bound"] = n_unk ** 3 / 3.0 / solve_s / 1e12

@@ -75,7 +75,10 @@ typedef struct BaOptions {
     double f_scale;        /*                      <- loss_f_scale (:214) */
     double ftol, xtol, gtol; /*                    <- 1e-8 each (:216-218) */
     double lambda0;        /* initial LM damping (default 1e-4) */
-    double pcg_tol;        /* relative residual of the reduced-camera-system solve (default 1e-8) */
+    double pcg_tol;        /* relative residual at which the ITERATIVE solves of the reduced camera system stop (PCG, preconditioned CG;
+                              the direct solvers ignore it).  > 0: that tolerance at every step.  0 (default): adaptive, an inexact-Newton
+                              forcing term eta = 1e-2 min(0.5, |g|inf) -- scipy's own lsmr_tol = 'auto' rule (_lsq/dogbox.py); the
+                              reference's TRF runs lsmr at its default atol = btol = 1e-6 (_lsq/trf.py) */
     int32_t pcg_max_iter;  /* default 500 */
     int32_t linear_solver; /* BA_SOLVER_*: AUTO = dense Cholesky up to 128 free cameras; block cyclic reduction when
                               co-visible free cameras are at most 21 apart along a chain or a closed ring (in camera order,

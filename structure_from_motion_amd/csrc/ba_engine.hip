@@ -594,6 +594,21 @@ int read_state(BaHandle *h) {
     return BA_OK;
 }
 
+// Relative residual at which the iterative solves of this step stop.  BaOptions.pcg_tol > 0: that, every step.
+// pcg_tol = 0 (the default): an inexact-Newton forcing term, eta = 1e-2 min(0.5, |g|inf) -- the rule of scipy's own
+// lsmr_tol = 'auto' (scipy/optimize/_lsq/dogbox.py; the reference's TRF runs lsmr at atol = btol = 1e-6,
+// BundleAdjustment.py:210-220 with scipy/optimize/_lsq/trf.py) -- loose while the LM step is far from the minimum (the
+// damping absorbs an inexact step: same number of LM steps, same minimum on every shape of the bench at a third of the
+// iterations), tightening with the gradient as the steps become Newton steps.  |g|inf is the handle's latest read-back
+// (the state one build ago at worst), identical on every rank of a sharded solve.
+double pcg_tol_now(const BaHandle *h) {
+    if (h->opt.pcg_tol > 0.0) return h->opt.pcg_tol;
+    const double g = h->hstate.gmax;
+    double eta = 1e-2 * (g < 0.5 ? g : 0.5);
+    if (!(eta > 1e-10)) eta = 1e-10;
+    return eta;
+}
+
 // block-Jacobi PCG on S x = -g_red; result in h->px
 int do_pcg(BaHandle *h, int *iters_out) {
     hipStream_t st = h->stream;
@@ -616,9 +631,9 @@ int do_pcg(BaHandle *h, int *iters_out) {
         pp.nb_cam = nb_cam; pp.nb_row = nb_row;
     }
     hipLaunchKernelGGL(k_pcg_init, dim3(nb_cam), dim3(256), 0, st, nf, h->gred, h->Minv.p, h->px.p, h->pr.p, h->pz.p, pp);
-    const double tol2 = h->opt.pcg_tol * h->opt.pcg_tol;
+    const double tol_now = pcg_tol_now(h), tol2 = tol_now * tol_now;
     const int max_it = h->opt.pcg_max_iter > 0 ? h->opt.pcg_max_iter : 500;
-    const int batch = 16;
+    const int batch = h->opt.pcg_tol > 0.0 ? 16 : 8;   // (iterations queued between two polls of the convergence flag)
     int it = 0;
     while (it < max_it) {
         const int end = std::min(max_it, it + batch);
@@ -786,7 +801,7 @@ int do_bcr_pcg(BaHandle *h, int *iters_out, bool *ok) {
         pp.nb_cam = nb_cam; pp.nb_row = nb_row;
     }
     hipLaunchKernelGGL(k_pcgx_init, dim3(nb_cam), dim3(256), 0, st, nf, h->gred, h->pz.p, h->px.p, h->pr.p, pp);
-    const double tol2 = h->opt.pcg_tol * h->opt.pcg_tol;
+    const double tol_now = pcg_tol_now(h), tol2 = tol_now * tol_now;
     // (with a useful preconditioner CG converges in a handful of iterations; one that has not after BCR_PCG_CAP is no
     // help on this problem: the plan is dropped and block-Jacobi PCG takes over, this step and from now on)
     constexpr int BCR_PCG_CAP = 120;
@@ -1032,7 +1047,7 @@ int check_options(BaOptions &o) {
     if (!(o.f_scale > 0.0)) return fail(BA_ERR_INVALID, "f_scale must be positive");
     if (o.loss < 0 || o.loss > 4) return fail(BA_ERR_INVALID, "unknown loss");
     if (!(o.lambda0 > 0.0)) o.lambda0 = 1e-4;
-    if (!(o.pcg_tol > 0.0)) o.pcg_tol = 1e-8;
+    if (!(o.pcg_tol > 0.0)) o.pcg_tol = 0.0;   // adaptive (pcg_tol_now)
     if (!(o.curv_floor > 0.0) || o.curv_floor > 1.0) o.curv_floor = 0.1;
     o.deterministic = o.deterministic ? 1 : 0;
     if (o.schur_mode < 0 || o.schur_mode > 2) return fail(BA_ERR_INVALID, "schur_mode must be 0 (auto), 1 (chunks) or 2 (rows)");
@@ -1348,7 +1363,7 @@ void ba_default_options(BaOptions *o) {
     o->f_scale = 1.0;
     o->ftol = o->xtol = o->gtol = 1e-8;
     o->lambda0 = 1e-4;
-    o->pcg_tol = 1e-8;
+    o->pcg_tol = 0.0;   // adaptive forcing term (pcg_tol_now)
     o->pcg_max_iter = 500;
     o->linear_solver = BA_SOLVER_AUTO;
     o->verbose = 0;

@@ -909,3 +909,27 @@ def test_cyclic_reduction_preconditioner_sweeps_equal_its_direct_solve(gpu):
         with _capi.Handle(_capi.Arrays.from_dict(p), loss="huber", f_scale=1.0) as h:
             h.build(1e-3)
             assert h.debug_bcr_apply() < 1e-9
+
+
+def test_adaptive_linear_solve_tolerance(gpu):
+    """BaOptions.pcg_tol = 0 (the default): the iterative solves stop at the inexact-Newton forcing term
+    eta = 1e-2 min(0.5, |g|inf) -- scipy's lsmr_tol='auto' rule; the reference's TRF runs lsmr at 1e-6
+    (BundleAdjustment.py:210-220) -- instead of a fixed tight tolerance.  The LM path is the same to four digits after 30
+    steps at a fraction of the CG iterations (the damping absorbs an inexact step): the ring with revisits (CG
+    preconditioned by the cyclic reduction) and unstructured co-visibility (block-Jacobi PCG)."""
+    cases = [("revisit", synthetic.make_ring(400, 20000, seed=72, mean_track=6.0, max_track=18, n_fixed=2, outlier_frac=0.01, radius=60.0,
+                                             point_radius=(4.0, 20.0), revisit_frac=0.01), "auto"),
+             ("random", synthetic.make_ring(150, 5000, seed=9, K=(1200.0, 1200.0, 960.0, 540.0), noise=0.5, visibility="random",
+                                            mean_track=7.0, max_track=14, n_fixed=2, radius=6.0), "pcg")]
+    for name, p, solver in cases:
+        res = {}
+        for tag, tol in (("tight", 1e-10), ("adaptive", 0.0)):
+            arr = _capi.Arrays.from_dict(p)
+            s = _capi.solve(arr, loss="huber", f_scale=1.0, max_iter=30, linear_solver=solver, pcg_tol=tol, pcg_max_iter=3000)
+            res[tag] = s
+        t, a = res["tight"], res["adaptive"]
+        print("%s: tight %d LM steps / %d CG iterations -> %.6e, adaptive %d / %d -> %.6e"
+              % (name, t["iterations"], t["pcg_iterations"], t["final_cost"], a["iterations"], a["pcg_iterations"], a["final_cost"]))
+        assert t["pcg_iterations"] > 0 and a["pcg_iterations"] <= 0.6 * t["pcg_iterations"]   # (measured: 298 of 1240, 132 of 244)
+        assert a["accepted"] >= t["accepted"] - 2 and a["final_cost"] < 0.2 * a["initial_cost"]
+        assert abs(a["final_cost"] - t["final_cost"]) <= 1e-4 * t["final_cost"]
