@@ -9,12 +9,13 @@
 #include <vector>
 
 #include "../include/ba_hip.h"
+#include "../structure_from_motion_amd/csrc/ba_symbolic.h"
 
 int main(int argc, char **argv) {
     const int n_cases = argc > 1 ? atoi(argv[1]) : 200;
     std::mt19937_64 rng(12345);
     auto uni = [&](int lo, int hi) { return (int)(lo + rng() % (uint64_t)(hi - lo + 1)); };
-    int plans = 0, analyses = 0, rejected = 0;
+    int plans = 0, analyses = 0, rows_analyses = 0, rejected = 0;
     for (int cs = 0; cs < n_cases; ++cs) {
         // ---- a random problem: chain / ring / random visibility, odd sizes, unobserved points, fixed cameras anywhere
         const int nc = uni(1, cs % 7 == 0 ? 900 : 120), np = uni(1, 3000), kind = uni(0, 3);
@@ -54,6 +55,26 @@ int main(int argc, char **argv) {
         BaAnalysis A{};
         const int e = ba_analyze(&P, &A);
         if (e == BA_OK) ++analyses; else ++rejected;
+        if (e == BA_OK) {
+            // the rows mode of the analysis (global per-block entry lists): every entry inside its block, blocks ascending
+            ba::Symbolic s;
+            const char *msg = "";
+            if (ba::analyze_structure(nc, np, (int64_t)oc.size(), fixed.data(), oc.data(), op.data(), s, &msg, false, true) != BA_OK) { fprintf(stderr, "rows analysis refused: %s\n", msg); return 1; }
+            ba::finalize_pattern(s, {});
+            if (s.rw_ptr.size() != s.raw_keys.size() + 1 || (int64_t)s.rw_ent.size() != 2 * s.rw_ptr.back()) { fprintf(stderr, "rows tables: sizes\n"); return 1; }
+            for (size_t k = 0; k < s.raw_keys.size(); ++k) {
+                if (k && s.raw_keys[k] <= s.raw_keys[k - 1]) { fprintf(stderr, "rows tables: keys not ascending\n"); return 1; }
+                if (s.rw_ptr[k + 1] <= s.rw_ptr[k]) { fprintf(stderr, "rows tables: empty block\n"); return 1; }
+                const int fi = (int)(s.raw_keys[k] >> 32), fj = (int)(s.raw_keys[k] & 0xffffffff);
+                if (s.upper_keys[s.ck_pair_slot[k]] != s.raw_keys[k]) { fprintf(stderr, "rows tables: slot\n"); return 1; }
+                for (int64_t q = s.rw_ptr[k]; q < s.rw_ptr[k + 1]; ++q) {
+                    const int32_t oi = s.rw_ent[2 * q], oj = s.rw_ent[2 * q + 1];
+                    if (oi < 0 || oj < 0 || oi >= (int64_t)oc.size() || oj >= (int64_t)oc.size() || s.o_pt[oi] != s.o_pt[oj] ||
+                        s.cam_free[s.o_cam[oi]] != fi || s.cam_free[s.o_cam[oj]] != fj) { fprintf(stderr, "rows tables: entry\n"); return 1; }
+                }
+            }
+            ++rows_analyses;
+        }
         // ---- a random pattern for the planner: band / ring / band + chords / random, with a random relabelling
         const int nf = uni(1, cs % 5 == 0 ? 2500 : 400), band = uni(0, 26), pk = uni(0, 3);
         std::vector<int> lab(nf);
@@ -80,6 +101,6 @@ int main(int argc, char **argv) {
         if (ba_bcr_plan(nf, pairs.data(), (int64_t)pr.size(), out.data(), need, &need) != BA_OK) { ++rejected; continue; }
         plans += out[0];
     }
-    printf("cases %d: analyses ok %d, refused %d, patterns with a schedule %d\n", n_cases, analyses, rejected, plans);
+    printf("cases %d: analyses ok %d (rows mode checked %d), refused %d, patterns with a schedule %d\n", n_cases, analyses, rows_analyses, rejected, plans);
     return 0;
 }
