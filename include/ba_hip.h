@@ -39,8 +39,8 @@ extern "C" {
 #define BA_ERR_NUMERIC (-5)     /* non-finite initial cost */
 #define BA_ERR_COMM (-6)        /* the all-reduce callback reported a failure */
 
-#define BA_MAX_TRACK 256 /* longest track on the fused chunk path; longer tracks ("heavy points") are eliminated by their
-                            own, slower kernels (one workgroup per point), any length */
+#define BA_MAX_TRACK 256 /* longest track on the fused chunk path; longer tracks ("heavy points", any length) are linearised
+                            by a workgroup each and their pairs accumulated from global per-block lists (csrc/ba_rows.h) */
 
 /* loss kinds = what scipy.optimize.least_squares accepts (scipy _lsq/least_squares.py:208-209);
  * the reference only uses 'huber' (BundleAdjustment.py:332, :367). */
@@ -106,7 +106,7 @@ typedef struct BaOptions {
                               pair groups hold hardly more than one entry each); 0 (default) = AUTO: chunks, unless the analysis
                               finds fewer than three entries per group on average (BaAnalysis.auto_rows_mode).  Belongs to the
                               analysed structure like `deterministic`; with deterministic = 1 the rows mode is taken as it is (its
-                              kernels have no atomics) unless the problem has heavy points, then the chunks */
+                              kernels have no atomics) */
     double curv_floor;     /* Hessian weight of a residual component = max(rho' + 2 rho'' z, curv_floor * rho');
                               1.0 = plain IRLS, default 0.1 (in (0, 1]) */
 } BaOptions;

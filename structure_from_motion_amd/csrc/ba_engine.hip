@@ -340,9 +340,10 @@ struct BaHandle {
     DevBuf<double> det_cam_slab, det_blk_slab;
     // rows mode (ba_rows.h): per-observation rows, global entry lists
     DevBuf<double> rows_buf;
-    DevBuf<int> rw_ent, rw_xblk, rw_diag;
+    DevBuf<int> rw_ent, rw_xblk, rw_diag, rw_slot;
     DevBuf<long long> rw_ptr;
     int rw_nx = 0;
+    long long rw_rows = 0, rw_row_off = 0;   // rows held by rows_buf, observation index of the first of them
     DevBuf<double> dense_a;          // dense reduced system (one-workgroup solver, or the blocked multi-workgroup one)
     DevBuf<double> dense_linv;       // blocked solver: inverse factors of the diagonal blocks
     DevBuf<double> band_l, band_y, band_g, band_mid;  // block-banded factor, work vectors, separator system
@@ -408,6 +409,7 @@ int upload_pattern(BaHandle *h) {
     const int nf = s.n_free;
     HIPCHK(h->ck_pair_slot.upload(s.ck_pair_slot, st));
     HIPCHK(h->hv_pair_slot.upload(s.hv_pair_slot, st));
+    HIPCHK(h->rw_slot.upload(s.rw_slot, st));
     HIPCHK(h->diag_slot.upload(s.diag_slot, st));
     HIPCHK(h->bsr_row.upload(s.bsr_row, st));
     HIPCHK(h->bsr_col.upload(s.bsr_col, st));
@@ -518,22 +520,30 @@ int do_build(BaHandle *h, bool timed) {
     // (deterministic build: k_det_reduce writes every element of S, U, g_c, g_red -- only the sums and the tail are cleared)
     // (rows mode: every block of S that has an entry is STORED by its owner; when these are all the blocks of the pattern -- no
     // block that only another rank or a heavy point contributes to -- S needs no clearing either)
-    const bool rows_all = h->sym.rows && h->n_heavy == 0 && h->n_chunks > 0 && (int)h->sym.raw_keys.size() == h->n_upper;
+    const bool rows_all = h->sym.rows && (int)h->sym.rw_keys.size() == h->n_upper;
     if (det) HIPCHK(hipMemsetAsync(h->red.p + nred - 4, 0, (4 + BA_MAX_WORLD) * sizeof(double), st));
     else if (rows_all) HIPCHK(hipMemsetAsync(h->red.p + (size_t)h->n_upper * 36, 0, (nred - (size_t)h->n_upper * 36 + BA_MAX_WORLD) * sizeof(double), st));
     else HIPCHK(hipMemsetAsync(h->red.p, 0, (nred + BA_MAX_WORLD) * sizeof(double), st));
     if (timed) HIPCHK(hipEventRecord(h->ev0, st));
+    RowsArgs R{};
+    R.rows = h->rows_buf.p; R.tails = h->rows_buf.p + (size_t)std::max<long long>(h->rw_rows, 1) * ROW_A; R.ent = h->rw_ent.p; R.ptr = h->rw_ptr.p;
+    R.key_slot = h->rw_slot.p; R.row_off = h->rw_row_off; R.xblk = h->rw_xblk.p; R.diag_key = h->rw_diag.p; R.n_x = h->rw_nx;
+    // heavy points (tracks no chunk holds): their rows come from k_lin_heavy, their pairs sit in the global entry lists
+    auto lin_heavy = [&]() {
+        if (h->opt.loss == BA_LOSS_HUBER) hipLaunchKernelGGL((k_lin_heavy<BA_LOSS_HUBER>), dim3(h->n_heavy), dim3(256), 0, st, build_args(h), heavy_args(h), R.rows, R.tails, R.row_off);
+        else hipLaunchKernelGGL((k_lin_heavy<-1>), dim3(h->n_heavy), dim3(256), 0, st, build_args(h), heavy_args(h), R.rows, R.tails, R.row_off);
+    };
     if (h->n_chunks > 0 && det) {
         if (h->opt.loss == BA_LOSS_HUBER) hipLaunchKernelGGL((k_build_det<BA_LOSS_HUBER>), dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, build_args(h), det_args(h));
         else hipLaunchKernelGGL((k_build_det<-1>), dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, build_args(h), det_args(h));
-    } else if (h->n_chunks > 0 && h->sym.rows) {
-        RowsArgs R{};
-        R.rows = h->rows_buf.p; R.tails = h->rows_buf.p + (size_t)std::max<int64_t>(h->sym.n_obs, 1) * ROW_A; R.ent = h->rw_ent.p; R.ptr = h->rw_ptr.p; R.key_slot = h->ck_pair_slot.p;
-        R.xblk = h->rw_xblk.p; R.diag_key = h->rw_diag.p; R.n_x = h->rw_nx;
-        if (h->opt.loss == BA_LOSS_HUBER) hipLaunchKernelGGL((k_lin<BA_LOSS_HUBER>), dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, build_args(h), R.rows, R.tails);
-        else hipLaunchKernelGGL((k_lin<-1>), dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, build_args(h), R.rows, R.tails);
-        if (nf > 0) hipLaunchKernelGGL(k_rows_diag, dim3(nf), dim3(256), 0, st, R, h->S, h->U, h->gc, h->gred);
-        if (h->rw_nx > 0) hipLaunchKernelGGL(k_rows_cross, dim3((h->rw_nx + 127) / 128), dim3(256), 0, st, R, h->S);
+    } else if (h->sym.rows) {
+        if (h->n_chunks > 0) {
+            if (h->opt.loss == BA_LOSS_HUBER) hipLaunchKernelGGL((k_lin<BA_LOSS_HUBER>), dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, build_args(h), R.rows, R.tails);
+            else hipLaunchKernelGGL((k_lin<-1>), dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, build_args(h), R.rows, R.tails);
+        }
+        if (h->n_heavy > 0) lin_heavy();
+        if (nf > 0 && h->n_chunks + h->n_heavy > 0) hipLaunchKernelGGL((k_rows_diag<false>), dim3(nf), dim3(256), 0, st, R, h->S, h->U, h->gc, h->gred);
+        if (h->rw_nx > 0) hipLaunchKernelGGL((k_rows_cross<false>), dim3((h->rw_nx + 127) / 128), dim3(256), 0, st, R, h->S);
     } else if (h->n_chunks > 0) {
         BuildArgs A = build_args(h);
         if (h->stamps.n) {
@@ -547,7 +557,14 @@ int do_build(BaHandle *h, bool timed) {
         }
     }
     if (timed) HIPCHK(hipEventRecord(h->ev1, st));
-    if (h->n_heavy > 0) hipLaunchKernelGGL(k_build_heavy, dim3(h->n_heavy), dim3(256), 0, st, build_args(h), heavy_args(h), det_args(h));
+    if (h->n_heavy > 0 && det) {
+        hipLaunchKernelGGL(k_build_heavy, dim3(h->n_heavy), dim3(256), 0, st, build_args(h), heavy_args(h), det_args(h));
+    } else if (h->n_heavy > 0 && !h->sym.rows) {
+        // chunk mode: the lists hold the heavy points only; their blocks are ADDED behind k_build (one owner per block)
+        lin_heavy();
+        if (nf > 0) hipLaunchKernelGGL((k_rows_diag<true>), dim3(nf), dim3(256), 0, st, R, h->S, h->U, h->gc, h->gred);
+        if (h->rw_nx > 0) hipLaunchKernelGGL((k_rows_cross<true>), dim3((h->rw_nx + 127) / 128), dim3(256), 0, st, R, h->S);
+    }
     if (det) {
         const long long n_el = (long long)h->n_upper * 36 + (long long)nf * 33;
         if (n_el > 0)
@@ -1094,7 +1111,6 @@ int build_structure(BaHandle *h, const HostProblem &hp, int n_cams, int n_points
     int e;
     const char *msg = "";
     // BaOptions.schur_mode: 0 AUTO (chunks; rows when the chunk-local groups are mostly padding), 1 chunks, 2 rows.
-    // deterministic + rows: only without heavy points (k_build_heavy adds to what the rows kernels stored with atomics).
     const bool det = h->opt.deterministic != 0;
     auto analyse = [&](bool rows) -> int {
         const int rc = analyze_structure(n_cams, n_points, n_obs, hp.cam_fixed.data(), hp.obs_cam.data(), hp.obs_pt.data(), h->sym, &msg, det, rows);
@@ -1102,7 +1118,6 @@ int build_structure(BaHandle *h, const HostProblem &hp, int n_cams, int n_points
     };
     if ((e = analyse(h->opt.schur_mode == 2))) return e;
     if (h->opt.schur_mode == 0 && wants_rows_mode(h->sym) && (double)n_obs * ROW_DOUBLES * 8 < 16e9 && (e = analyse(true))) return e;
-    if (det && h->sym.rows && h->sym.n_heavy > 0 && (e = analyse(false))) return e;
     const bool tm_on = getenv("BA_TIME") != nullptr;
     double tl = now_ms();
     finalize_pattern(h->sym, {});
@@ -1115,7 +1130,8 @@ int build_structure(BaHandle *h, const HostProblem &hp, int n_cams, int n_points
         std::vector<long long> ho(s.hv_obs.begin(), s.hv_obs.end()), hq(s.hv_pair.begin(), s.hv_pair.end());
         HIPCHK(h->hv_obs.upload(ho, st));
         HIPCHK(h->hv_pair.upload(hq, st));
-        HIPCHK(h->hv_t.alloc((size_t)(s.hv_obs.back() - s.hv_obs.front()) * 18));
+        if (!s.hv_keys.empty()) HIPCHK(h->hv_t.alloc((size_t)(s.hv_obs.back() - s.hv_obs.front()) * 18));   // (k_build_heavy: deterministic chunk mode)
+        else h->hv_t.release();
     }
     HIPCHK(h->cam_free.upload(s.cam_free, st));
     HIPCHK(h->free_cam.upload(s.free_cam, st));
@@ -1134,22 +1150,27 @@ int build_structure(BaHandle *h, const HostProblem &hp, int n_cams, int n_points
     HIPCHK(h->pair_entries.upload(s.pair_entries, st));
     HIPCHK(h->ck_pgrp.upload(s.ck_pgrp, st));
     h->rw_nx = 0;
-    if (s.rows) {
+    h->rw_rows = h->rw_row_off = 0;
+    if (s.rows || !s.rw_keys.empty()) {
+        // rows mode: every observation has a row; chunk mode: the heavy points' observations (the last of the internal order)
+        h->rw_row_off = s.rows ? 0 : (long long)s.hv_obs.front();
+        h->rw_rows = (long long)s.n_obs - h->rw_row_off;
         std::vector<int32_t> xblk, diag((size_t)std::max(s.n_free, 1), -1);
-        for (size_t k = 0; k < s.raw_keys.size(); ++k) {
-            const int i = (int)(s.raw_keys[k] >> 32), j = (int)(s.raw_keys[k] & 0xffffffff);
+        for (size_t k = 0; k < s.rw_keys.size(); ++k) {
+            const int i = (int)(s.rw_keys[k] >> 32), j = (int)(s.rw_keys[k] & 0xffffffff);
             if (i == j) diag[i] = (int32_t)k;
             else xblk.push_back((int32_t)k);
         }
         h->rw_nx = (int)xblk.size();
         if (xblk.empty()) xblk.push_back(0);
         std::vector<long long> ptr(s.rw_ptr.begin(), s.rw_ptr.end());
+        if (ptr.empty()) ptr.push_back(0);
         if (s.rw_ent.empty()) s.rw_ent.assign(2, 0);
         HIPCHK(h->rw_ent.upload(s.rw_ent, st));
         HIPCHK(h->rw_ptr.upload(ptr, st));
         HIPCHK(h->rw_xblk.upload(xblk, st));
         HIPCHK(h->rw_diag.upload(diag, st));
-        HIPCHK(h->rows_buf.alloc_grow((size_t)std::max<int64_t>(s.n_obs, 1) * ROW_DOUBLES));
+        HIPCHK(h->rows_buf.alloc_grow((size_t)std::max<long long>(h->rw_rows, 1) * ROW_DOUBLES));
     } else {
         h->rows_buf.release(); h->rw_ent.release(); h->rw_ptr.release(); h->rw_xblk.release(); h->rw_diag.release();
     }

@@ -17,9 +17,11 @@
 //     of the reduced gradient and the diagonal block, summed over the lanes in a fixed order.
 // Every floating-point sum of these three kernels has a fixed order (k_lin gathers each point's sums over its consecutive
 // lanes): without heavy points two passes over the same state give the same bits.
-// The host builds the lists once per structure (analyze_structure(..., rows); Symbolic::rw_ent / rw_ptr).  Heavy points keep
-// their own kernel, which adds to S, U, g with atomics after these kernels have stored.
+// The host builds the lists once per structure (analyze_structure(..., rows); Symbolic::rw_ent / rw_ptr).  Heavy points (tracks
+// no chunk holds) get their rows from k_lin_heavy and sit in the same lists; in the CHUNK mode the lists hold the heavy points
+// only and the ADD variants of k_rows_* run behind k_build.
 #pragma once
+#include "ba_heavy.h"
 #include "ba_kernels.h"
 
 namespace ba {
@@ -31,7 +33,9 @@ struct RowsArgs {
     double *tails;                // [n_obs * ROW_B]: a, b, p02, p12, wh (2), w r (2)
     const int *ent;               // 2 per entry
     const long long *ptr;         // [n_keys + 1]
-    const int *key_slot;          // block slot of each key (= ck_pair_slot in this mode)
+    const int *key_slot;          // block slot of each key (Symbolic::rw_slot)
+    long long row_off;            // rows / tails are indexed by (observation - row_off): 0 in the rows mode, the first heavy
+                                  // observation in the chunk mode (rows of the heavy points only)
     const int *xblk;              // keys of the off-diagonal blocks
     const int *diag_key;          // [n_free] key of the camera's diagonal block, or -1
     int n_x;
@@ -191,7 +195,7 @@ __device__ __forceinline__ void schur_entry(const double *__restrict__ Ti, const
     }
 }
 
-__device__ __forceinline__ void load_row12(const double *__restrict__ rows, int o, double *__restrict__ T, double *__restrict__ Y) {
+__device__ __forceinline__ void load_row12(const double *__restrict__ rows, long long o, double *__restrict__ T, double *__restrict__ Y) {
     const double2 *q = reinterpret_cast<const double2 *>(rows + (size_t)o * ROW_A);
     const double2 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3], v4 = q[4], v5 = q[5];
     T[0] = v0.x; T[1] = v0.y; T[2] = v1.x; T[3] = v1.y; T[4] = v2.x; T[5] = v2.y; T[6] = v3.x; T[7] = v3.y; T[8] = v4.x;
@@ -199,6 +203,9 @@ __device__ __forceinline__ void load_row12(const double *__restrict__ rows, int 
 }
 
 // One lane pair per off-diagonal block with entries; lane h of the pair takes entries 4 h .. 4 h + 3 of every run of eight.
+// ADD: the blocks are added to (chunk mode: the heavy points' pairs on top of what the chunk kernel accumulated; every
+// block still has ONE owner here, and the launch is ordered behind the chunk kernel: plain read-modify-write).
+template <bool ADD>
 __global__ __launch_bounds__(256) void k_rows_cross(const RowsArgs R, double *__restrict__ S) {
     const int tid = threadIdx.x, half = tid & 1;
     const int g = blockIdx.x * 128 + (tid >> 1);
@@ -218,8 +225,8 @@ __global__ __launch_bounds__(256) void k_rows_cross(const RowsArgs R, double *__
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             double Ti[9], Yi[3], Tj[9], Yj[3];
-            load_row12(R.rows, oi[e], Ti, Yi);
-            load_row12(R.rows, oj[e], Tj, Yj);
+            load_row12(R.rows, oi[e] - R.row_off, Ti, Yi);
+            load_row12(R.rows, oj[e] - R.row_off, Tj, Yj);
             if (base + e < e1) schur_entry(Ti, Yi, Tj, Yj, acc);
         }
     }
@@ -229,10 +236,10 @@ __global__ __launch_bounds__(256) void k_rows_cross(const RowsArgs R, double *__
         double *d = S + (size_t)R.key_slot[key] * 36;
         if (half == 0) {
 #pragma unroll
-            for (int k = 0; k < 18; ++k) d[k] = -acc[k];
+            for (int k = 0; k < 18; ++k) d[k] = (ADD ? d[k] : 0.0) - acc[k];
         } else {
 #pragma unroll
-            for (int k = 18; k < 36; ++k) d[k] = -acc[k];
+            for (int k = 18; k < 36; ++k) d[k] = (ADD ? d[k] : 0.0) - acc[k];
         }
     }
 }
@@ -240,6 +247,7 @@ __global__ __launch_bounds__(256) void k_rows_cross(const RowsArgs R, double *__
 // One workgroup per free camera: the entries of its diagonal block are its observations (i, i) -- each also gives the
 // camera's U, g_c and its part of the reduced gradient -- and, for a camera that sees a point twice, the pairs (i, j), (j, i).
 constexpr int DIAG_VALS = 36 + 21 + 6 + 6;
+template <bool ADD>
 __global__ __launch_bounds__(256) void k_rows_diag(const RowsArgs R, double *__restrict__ S, double *__restrict__ U, double *__restrict__ gc,
                                                    double *__restrict__ gred) {
     __shared__ double sW[4][DIAG_VALS];
@@ -257,12 +265,12 @@ __global__ __launch_bounds__(256) void k_rows_diag(const RowsArgs R, double *__r
     for (long long e = e0 + tid; e < e1; e += 256) {
         const int2 v = reinterpret_cast<const int2 *>(R.ent)[e];
         double Ti[9], Yi[3], Tj[9], Yj[3];
-        load_row12(R.rows, v.x, Ti, Yi);
-        load_row12(R.rows, v.y, Tj, Yj);
+        load_row12(R.rows, v.x - R.row_off, Ti, Yi);
+        load_row12(R.rows, v.y - R.row_off, Tj, Yj);
         schur_entry(Ti, Yi, Tj, Yj, acc);
         if (v.x == v.y) {
-            const double2 *q = reinterpret_cast<const double2 *>(R.rows + (size_t)v.x * ROW_A);
-            const double2 *qt = reinterpret_cast<const double2 *>(R.tails + (size_t)v.x * ROW_B);
+            const double2 *q = reinterpret_cast<const double2 *>(R.rows + (size_t)(v.x - R.row_off) * ROW_A);
+            const double2 *qt = reinterpret_cast<const double2 *>(R.tails + (size_t)(v.x - R.row_off) * ROW_B);
             const double2 t6 = q[6], t7 = q[7], t8 = qt[0], t9 = qt[1], t10 = qt[2], t11 = qt[3];
             const double w0 = t6.x, w1 = t6.y, w2 = t7.x;
             gr[0] += Yi[1] * w2 - Yi[2] * w1;
@@ -299,10 +307,112 @@ __global__ __launch_bounds__(256) void k_rows_diag(const RowsArgs R, double *__r
     __syncthreads();
     if (tid < DIAG_VALS) {
         const double v = (sW[0][tid] + sW[1][tid]) + (sW[2][tid] + sW[3][tid]);
-        if (tid < 36) S[(size_t)R.key_slot[key] * 36 + tid] = -v;
-        else if (tid < 57) U[(size_t)f * 21 + (tid - 36)] = v;
-        else if (tid < 63) gc[(size_t)f * 6 + (tid - 57)] = v;
-        else gred[(size_t)f * 6 + (tid - 63)] = -v;
+        double *dst = tid < 36 ? &S[(size_t)R.key_slot[key] * 36 + tid] : tid < 57 ? &U[(size_t)f * 21 + (tid - 36)]
+                                                                           : tid < 63 ? &gc[(size_t)f * 6 + (tid - 57)] : &gred[(size_t)f * 6 + (tid - 63)];
+        const double sv = (tid < 36 || tid >= 63) ? -v : v;
+        *dst = ADD ? *dst + sv : sv;
+    }
+}
+
+// k_lin for a HEAVY point (a track no chunk holds): one workgroup, the point's observations in strides of 256.  Pass 1 sums
+// V, g_p and the cost (fixed order), every thread factors the damped block, pass 2 writes the observations' rows and tails;
+// the point's pairs then go through k_rows_* like everybody else's (the first version of the heavy path added every pair's
+// block to S with 36 atomics from one workgroup per point: 20 ms per landmark seen by 1 778 cameras).
+template <int LOSS>
+__global__ __launch_bounds__(256) void k_lin_heavy(const BuildArgs A, const HeavyArgs H, double *__restrict__ rows, double *__restrict__ tails,
+                                                   long long row_off) {
+    __shared__ double sRed[4];
+    const int hp = blockIdx.x, tid = threadIdx.x;
+    const long long ob = H.hv_obs[hp];
+    const int L = (int)(H.hv_obs[hp + 1] - ob);
+    const int p = H.pt0 + hp;
+    const int loss = LOSS >= 0 ? LOSS : A.loss;
+    const double lam = A.state->lambda, floor_now = A.state->floor;
+    const double X0 = A.points[3 * (size_t)p], X1 = A.points[3 * (size_t)p + 1], X2 = A.points[3 * (size_t)p + 2];
+    double vs[9], cost = 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) vs[k] = 0.0;
+    for (int o = tid; o < L; o += 256) {
+        const int cam = A.o_cam[ob + o];
+        const double2 xy = reinterpret_cast<const double2 *>(A.o_xy)[ob + o];
+        CamAux ca;
+        load_aux_local(A.aux, cam, ca);
+        ObsLin Ln;
+        linearize(ca, X0, X1, X2, xy.x, xy.y, loss, A.inv_fs2, floor_now, Ln);
+        cost += A.half_fs2 * Ln.rho_sum;
+        double wJp[2][3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { wJp[0][j] = Ln.wh[0] * Ln.Jp[0][j]; wJp[1][j] = Ln.wh[1] * Ln.Jp[1][j]; }
+        vs[0] += wJp[0][0] * Ln.Jp[0][0] + wJp[1][0] * Ln.Jp[1][0];
+        vs[1] += wJp[0][0] * Ln.Jp[0][1] + wJp[1][0] * Ln.Jp[1][1];
+        vs[2] += wJp[0][0] * Ln.Jp[0][2] + wJp[1][0] * Ln.Jp[1][2];
+        vs[3] += wJp[0][1] * Ln.Jp[0][1] + wJp[1][1] * Ln.Jp[1][1];
+        vs[4] += wJp[0][1] * Ln.Jp[0][2] + wJp[1][1] * Ln.Jp[1][2];
+        vs[5] += wJp[0][2] * Ln.Jp[0][2] + wJp[1][2] * Ln.Jp[1][2];
+        const double wr0 = Ln.w[0] * Ln.r[0], wr1 = Ln.w[1] * Ln.r[1];
+        vs[6] += Ln.Jp[0][0] * wr0 + Ln.Jp[1][0] * wr1;
+        vs[7] += Ln.Jp[0][1] * wr0 + Ln.Jp[1][1] * wr1;
+        vs[8] += Ln.Jp[0][2] * wr0 + Ln.Jp[1][2] * wr1;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) vs[k] = block_sum256(vs[k], sRed);
+    cost = block_sum256(cost, sRed);
+    const double v00 = vs[0], v01 = vs[1], v02 = vs[2], v11 = vs[3], v12 = vs[4], v22 = vs[5];
+    const double g0 = vs[6], g1 = vs[7], g2 = vs[8];
+    const double a00 = v00 + lam * fmin(fmax(v00, BA_D_MIN), BA_D_MAX);
+    const double a11 = v11 + lam * fmin(fmax(v11, BA_D_MIN), BA_D_MAX);
+    const double a22 = v22 + lam * fmin(fmax(v22, BA_D_MIN), BA_D_MAX);
+    const double i00 = rsqrt_nr(a00);
+    const double l10 = v01 * i00, l20 = v02 * i00;
+    const double i11 = rsqrt_nr(fmax(a11 - l10 * l10, 1e-15 * a11));
+    const double l21 = (v12 - l20 * l10) * i11;
+    const double i22 = rsqrt_nr(fmax(a22 - l20 * l20 - l21 * l21, 1e-15 * a22));
+    const double i10 = -l10 * i00 * i11;
+    const double i21 = -l21 * i11 * i22;
+    const double i20 = -(l20 * i00 + l21 * i10) * i22;
+    const double u0 = i00 * g0, u1 = i10 * g0 + i11 * g1, u2 = i20 * g0 + i21 * g1 + i22 * g2;
+    if (tid == 0) {
+        double *gl = &A.pt_linv[(size_t)p * 6];
+        gl[0] = i00; gl[1] = i10; gl[2] = i11; gl[3] = i20; gl[4] = i21; gl[5] = i22;
+        double *gu = &A.pt_u[(size_t)p * 3];
+        gu[0] = u0; gu[1] = u1; gu[2] = u2;
+        if (A.dbg_v) {
+            double *dv = &A.dbg_v[(size_t)p * 6];
+            dv[0] = v00; dv[1] = v01; dv[2] = v02; dv[3] = v11; dv[4] = v12; dv[5] = v22;
+            double *dg = &A.dbg_gp[(size_t)p * 3];
+            dg[0] = g0; dg[1] = g1; dg[2] = g2;
+        }
+        A.ck_cost[H.n_chunks + hp] = cost;
+        A.ck_gmax[H.n_chunks + hp] = fmax(fabs(g0), fmax(fabs(g1), fabs(g2)));
+    }
+    for (int o = tid; o < L; o += 256) {
+        const int cam = A.o_cam[ob + o];
+        if (A.cam_free[cam] < 0) continue;
+        const double2 xy = reinterpret_cast<const double2 *>(A.o_xy)[ob + o];
+        CamAux ca;
+        load_aux_local(A.aux, cam, ca);
+        ObsLin Ln;
+        linearize(ca, X0, X1, X2, xy.x, xy.y, loss, A.inv_fs2, floor_now, Ln);
+        double t[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double x0 = (Ln.wh[0] * Ln.Jc[0][3 + i]) * Ln.Jp[0][0] + (Ln.wh[1] * Ln.Jc[1][3 + i]) * Ln.Jp[1][0];
+            const double x1 = (Ln.wh[0] * Ln.Jc[0][3 + i]) * Ln.Jp[0][1] + (Ln.wh[1] * Ln.Jc[1][3 + i]) * Ln.Jp[1][1];
+            const double x2 = (Ln.wh[0] * Ln.Jc[0][3 + i]) * Ln.Jp[0][2] + (Ln.wh[1] * Ln.Jc[1][3 + i]) * Ln.Jp[1][2];
+            t[i * 3] = x0 * i00;
+            t[i * 3 + 1] = x0 * i10 + x1 * i11;
+            t[i * 3 + 2] = x0 * i20 + x1 * i21 + x2 * i22;
+        }
+        const double w0 = t[0] * u0 + t[1] * u1 + t[2] * u2, w1 = t[3] * u0 + t[4] * u1 + t[5] * u2,
+                     w2 = t[6] * u0 + t[7] * u1 + t[8] * u2;
+        const double wr0 = Ln.w[0] * Ln.r[0], wr1 = Ln.w[1] * Ln.r[1];
+        double2 *d = reinterpret_cast<double2 *>(rows + (size_t)(ob + o - row_off) * ROW_A);
+        d[0] = make_double2(t[0], t[1]); d[1] = make_double2(t[2], t[3]); d[2] = make_double2(t[4], t[5]);
+        d[3] = make_double2(t[6], t[7]); d[4] = make_double2(t[8], Ln.Y[0]); d[5] = make_double2(Ln.Y[1], Ln.Y[2]);
+        d[6] = make_double2(w0, w1); d[7] = make_double2(w2, 0.0);
+        double2 *q = reinterpret_cast<double2 *>(tails + (size_t)(ob + o - row_off) * ROW_B);
+        q[0] = make_double2(Ln.Jc[0][3], Ln.Jc[1][4]); q[1] = make_double2(Ln.Jc[0][5], Ln.Jc[1][5]);
+        q[2] = make_double2(Ln.wh[0], Ln.wh[1]); q[3] = make_double2(wr0, wr1);
     }
 }
 

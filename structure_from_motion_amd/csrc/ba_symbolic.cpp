@@ -155,39 +155,14 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
         track_sum += L;
     }
     tick("obs gather");
-    if (s.rows) {
-        // --- rows mode: chunks of whole points by observation / point count only; the Schur entries are global ------
-        s.ck_obs.push_back(0);
-        s.ck_pt.push_back(0);
-        int cur_obs = 0, cur_pts = 0;
-        for (int i = 0; i < s.n_pts_chunked; ++i) {
-            const int L = (int)(pstart[i + 1] - pstart[i]);
-            if (cur_pts > 0 && (cur_obs + L > CHUNK_OBS || cur_pts + 1 > CHUNK_PTS)) {
-                s.ck_obs.push_back((int32_t)pstart[i]);
-                s.ck_pt.push_back(i);
-                cur_obs = cur_pts = 0;
-            }
-            cur_obs += L;
-            cur_pts += 1;
-        }
-        if (cur_pts > 0) {
-            s.ck_obs.push_back((int32_t)pstart[s.n_pts_chunked]);
-            s.ck_pt.push_back(s.n_pts_chunked);
-        }
-        const size_t nck = s.ck_obs.size() - 1;
-        s.ck_cam.assign(nck + 1, 0);
-        s.ck_pair.assign(nck + 1, 0);
-        s.ck_pe.assign(nck + 1, 0);
-        s.ck_pgrp.assign(nck, 0);
-        parallel_for(pstart[s.n_pts_chunked], [&](int64_t lo, int64_t hi) {
-            for (int64_t k = lo; k < hi; ++k) s.o_lcam[k] = s.cam_free[s.o_cam[k]] < 0 ? -2 : -1;
-        });
-        tick("chunking (rows)");
+    // Global per-block entry lists (Symbolic::rw_*) of the points [pt_lo, pt_hi): the rows mode builds them for every point,
+    // the chunk mode for its heavy points (whose pairs no chunk can hold).
+    auto build_row_lists = [&](const int pt_lo, const int pt_hi) {
         // entries by block row: observations inside a point are sorted by camera, and free indices grow with the camera
         // index, so (a <= c) gives fa <= fc: the entry belongs to the upper block (fa, fc) as T_a T_c^T
         const int nf = s.n_free;
         std::vector<int64_t> rstart((size_t)nf + 1, 0);
-        for (int i = 0; i < s.n_pts_chunked; ++i) {
+        for (int i = pt_lo; i < pt_hi; ++i) {
             const int64_t b = pstart[i], e = pstart[i + 1];
             for (int64_t a = b; a < e; ++a) {
                 const int fa = s.cam_free[s.o_cam[a]];
@@ -205,7 +180,7 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
         std::vector<Ent> ents((size_t)n_ent);
         {
             std::vector<int64_t> fill(rstart.begin(), rstart.end() - 1);
-            for (int i = 0; i < s.n_pts_chunked; ++i) {
+            for (int i = pt_lo; i < pt_hi; ++i) {
                 const int64_t b = pstart[i], e = pstart[i + 1];
                 for (int64_t a = b; a < e; ++a) {
                     const int fa = s.cam_free[s.o_cam[a]];
@@ -244,15 +219,45 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
         for (int f = 0; f < nf; ++f)
             for (int64_t k = rstart[f]; k < rstart[f + 1]; ++k) {
                 if (k == rstart[f] || ents[k].fc != ents[k - 1].fc) {
-                    s.raw_keys.push_back(((int64_t)f << 32) | (uint32_t)ents[k].fc);
+                    s.rw_keys.push_back(((int64_t)f << 32) | (uint32_t)ents[k].fc);
                     s.rw_ptr.push_back(k);
                 }
                 s.rw_ent[2 * k] = ents[k].oi;
                 s.rw_ent[2 * k + 1] = ents[k].oj;
             }
         s.rw_ptr.push_back(n_ent);
-        s.n_pair_real = n_ent;
+        if (s.rows) s.n_pair_real += n_ent;
         tick("row blocks");
+    };
+    if (s.rows) {
+        // --- rows mode: chunks of whole points by observation / point count only; the Schur entries are global ------
+        s.ck_obs.push_back(0);
+        s.ck_pt.push_back(0);
+        int cur_obs = 0, cur_pts = 0;
+        for (int i = 0; i < s.n_pts_chunked; ++i) {
+            const int L = (int)(pstart[i + 1] - pstart[i]);
+            if (cur_pts > 0 && (cur_obs + L > CHUNK_OBS || cur_pts + 1 > CHUNK_PTS)) {
+                s.ck_obs.push_back((int32_t)pstart[i]);
+                s.ck_pt.push_back(i);
+                cur_obs = cur_pts = 0;
+            }
+            cur_obs += L;
+            cur_pts += 1;
+        }
+        if (cur_pts > 0) {
+            s.ck_obs.push_back((int32_t)pstart[s.n_pts_chunked]);
+            s.ck_pt.push_back(s.n_pts_chunked);
+        }
+        const size_t nck = s.ck_obs.size() - 1;
+        s.ck_cam.assign(nck + 1, 0);
+        s.ck_pair.assign(nck + 1, 0);
+        s.ck_pe.assign(nck + 1, 0);
+        s.ck_pgrp.assign(nck, 0);
+        parallel_for(pstart[s.n_pts_chunked], [&](int64_t lo, int64_t hi) {
+            for (int64_t k = lo; k < hi; ++k) s.o_lcam[k] = s.cam_free[s.o_cam[k]] < 0 ? -2 : -1;
+        });
+        tick("chunking (rows)");
+        build_row_lists(0, s.n_pts_chunked + s.n_heavy);
     } else {
     // --- greedy chunking -----------------------------------------------------------------
     // The point range is cut into up to CHUNK_THREADS parts (balanced by observations) that are chunked independently on
@@ -504,6 +509,9 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
     }   // (chunk mode)
     // --- heavy points (more observations than a chunk holds): one workgroup each (k_build_heavy), every (a <= c)
     // pair of the point's observations gets its block slot from a triangular list
+    // (the deterministic chunk mode keeps a triangular key list per heavy point for k_build_heavy's slab rows; every other
+    // mode takes the heavy points' pairs through the global entry lists: k_lin_heavy + k_rows_*)
+    const bool heavy_lists = s.deterministic && !s.rows;
     s.hv_obs.push_back(pstart[s.n_pts_chunked]);
     s.hv_pair.push_back(0);
     for (int i = s.n_pts_chunked; i < s.n_pts_chunked + s.n_heavy; ++i) {
@@ -512,7 +520,7 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
         for (int a = 0; a < L; ++a) {
             const int fa = s.cam_free[s.o_cam[b + a]];
             s.o_lcam[b + a] = fa < 0 ? -2 : -1;
-            for (int c = a; c < L; ++c) {
+            for (int c = a; heavy_lists && c < L; ++c) {
                 const int fc = s.cam_free[s.o_cam[b + c]];
                 int64_t key = -1;
                 if (fa >= 0 && fc >= 0) {
@@ -526,6 +534,7 @@ int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *ca
         s.hv_obs.push_back(e);
         s.hv_pair.push_back((int64_t)s.hv_keys.size());
     }
+    if (!s.rows && !heavy_lists && s.n_heavy > 0) build_row_lists(s.n_pts_chunked, s.n_pts_chunked + s.n_heavy);
     tick("heavy points");
     if (!s.rows) {
         long long groups = 0, pairs = 0;
@@ -553,12 +562,16 @@ void finalize_pattern(Symbolic &s, const std::vector<int64_t> &extra_keys) {
     keys.insert(keys.end(), extra_keys.begin(), extra_keys.end());
     for (int64_t k : s.hv_keys)
         if (k >= 0) keys.push_back(k & HV_KEY_MASK);
+    keys.insert(keys.end(), s.rw_keys.begin(), s.rw_keys.end());
     for (int f = 0; f < s.n_free; ++f) keys.push_back(((int64_t)f << 32) | (uint32_t)f);  // every diagonal block
     std::sort(keys.begin(), keys.end());
     keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
     s.upper_keys = keys;
     for (size_t k = 0; k < raw.size(); ++k)
         s.ck_pair_slot[k] = (int32_t)(std::lower_bound(keys.begin(), keys.end(), raw[k]) - keys.begin());
+    s.rw_slot.resize(s.rw_keys.size());
+    for (size_t k = 0; k < s.rw_keys.size(); ++k)
+        s.rw_slot[k] = (int32_t)(std::lower_bound(keys.begin(), keys.end(), s.rw_keys[k]) - keys.begin());
     s.hv_pair_slot.assign(s.hv_keys.size(), -1);
     for (size_t k = 0; k < s.hv_keys.size(); ++k) {
         const int64_t key = s.hv_keys[k];

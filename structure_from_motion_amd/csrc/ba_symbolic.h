@@ -73,14 +73,19 @@ struct Symbolic {
     int max_chunk_cams = 0, max_chunk_pairs = 0;
     bool deterministic = false;      // analysed for the atomic-free build (see analyze_structure)
     int64_t n_groups = 0;            // groups of pair entries over all chunks (chunk mode)
-    // "rows" mode (ba_rows.h): the Schur complement from GLOBAL per-block entry lists instead of chunk-local ones -- for
-    // co-visibility without structure inside a chunk (hardly two points of a chunk share a camera pair).  Chunks then only
-    // carry points and observations (no camera slots, no pairs); raw_keys holds every block (i <= j) that has an entry, in
-    // ascending order, ck_pair_slot its slot, and entries rw_ptr[k] .. rw_ptr[k + 1] of rw_ent the (observation i,
-    // observation j) pairs of block k, in point order (internal observation indices; T_i T_j^T goes to the block as stored).
+    // Global per-block entry lists (ba_rows.h): rw_keys holds, in ascending order, every block (i <= j) that has an entry,
+    // rw_slot its slot in the pattern, and entries rw_ptr[k] .. rw_ptr[k + 1] of rw_ent the (observation i, observation j)
+    // pairs of block k, in point order (internal observation indices; T_i T_j^T goes to the block as stored).
+    //   * "rows" mode: the lists of EVERY point -- the Schur complement is accumulated from them instead of inside the chunks,
+    //     for co-visibility without structure inside a chunk (hardly two points of a chunk share a camera pair).  Chunks
+    //     then only carry points and observations (no camera slots, no pairs).
+    //   * chunk mode (not deterministic): the lists of the HEAVY points only (tracks no chunk can hold); their blocks are
+    //     added on top of what the chunk kernel accumulated.
     bool rows = false;
+    std::vector<int64_t> rw_keys;
+    std::vector<int32_t> rw_slot;
     std::vector<int32_t> rw_ent;     // 2 per entry
-    std::vector<int64_t> rw_ptr;     // [raw_keys.size() + 1]
+    std::vector<int64_t> rw_ptr;     // [rw_keys.size() + 1]
 };
 
 // Contribution tables of the deterministic (atomic-free) build: every partial result of the build kernels has a slab
@@ -107,8 +112,7 @@ void build_det_tables(const Symbolic &s, DetTables &t);
 // Phase A: ordering + chunking + this problem's own pair keys.  Returns 0 or a BA_ERR_* code.
 // deterministic: the structure for the atomic-free build -- no chunk holds more cameras than it has local slots
 // (CHUNK_CAMS_WIDE), and a point seen by more cameras than that is a heavy point.
-// rows: the "rows" mode of the Schur complement (Symbolic::rows).  Together with deterministic it is only usable when the
-// analysis finds no heavy point (their kernel adds with atomics): the caller checks n_heavy and analyses again without it.
+// rows: the "rows" mode of the Schur complement (Symbolic::rows); its kernels have no atomics, so it goes with deterministic as it is.
 int analyze_structure(int n_cams, int n_points, int64_t n_obs, const uint8_t *cam_fixed,
                       const int32_t *obs_cam, const int32_t *obs_pt, Symbolic &s, const char **err, bool deterministic = false,
                       bool rows = false);

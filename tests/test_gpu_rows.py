@@ -26,8 +26,8 @@ def _problems():
     yield "street", synthetic.make_street(12, 300, 1300, seed=8, outlier_frac=0.05)
     yield "random", synthetic.make_ring(90, 1500, seed=78, K=(1200.0, 1200.0, 960.0, 540.0), focal_jitter=0.05, noise=0.5,
                                         outlier_frac=0.02, visibility="random", mean_track=7.0, max_track=20, n_fixed=2, radius=6.0)
-    # landmarks seen by every camera (heavy points keep their own kernel and add to what the rows kernels stored),
-    # unobserved points, two fixed cameras
+    # landmarks seen by every camera (heavy points: rows from k_lin_heavy, pairs in the same global lists), unobserved points,
+    # two fixed cameras
     yield "heavy", synthetic.make_ring(270, 110, seed=3, mean_track=30.0, max_track=60, n_landmarks=3, outlier_frac=0.05,
                                        n_fixed=2, n_unobserved=2)
     yield "long_tracks", synthetic.make_ring(400, 40, seed=79, K=(1200.0, 1200.0, 960.0, 540.0), focal_jitter=0.05, noise=0.5,
@@ -60,9 +60,8 @@ def test_rows_mode_reduced_system_against_the_oracle(gpu, name, p, loss):
         assert abs(h.cost() - nb["F"]) <= 1e-12 * nb["F"]
         h.build(lam)                                  # every sum of the three kernels has a fixed order: the same bits again
         r2 = h.reduced_system()
-        if name != "heavy":                           # (heavy points add with atomics)
-            for k in ("S", "gred", "U", "gc", "V", "gp"):
-                np.testing.assert_array_equal(r[k], r2[k])
+        for k in ("S", "gred", "U", "gc", "V", "gp"):
+            np.testing.assert_array_equal(r[k], r2[k])
 
 
 @pytest.mark.parametrize("solver", ["auto", "pcg"])
@@ -171,8 +170,8 @@ def test_rows_mode_full_size_orbit(gpu):
 @pytest.mark.parametrize("kind", ["random", "heavy"])
 def test_deterministic_flag_with_the_rows_mode(gpu, kind):
     """BaOptions.deterministic = 1 together with schur_mode = rows: the rows kernels have no atomics, so the mode is taken as it
-    is -- unless the problem has heavy points (their kernel adds with atomics), then the atomic-free chunk kernels of
-    ba_det.h take over.  Either way: two LM runs on fresh handles, every cost and every camera bit for bit."""
+    is, heavy points included (k_lin_heavy sums in a fixed order).  Two LM runs on fresh handles, every cost and every camera
+    bit for bit."""
     if kind == "random":
         p = synthetic.make_ring(60, 2500, seed=31, K=(1200.0, 1200.0, 960.0, 540.0), focal_jitter=0.05, noise=0.5, outlier_frac=0.02,
                                 visibility="random", mean_track=6.0, max_track=16, n_fixed=2, radius=6.0)
@@ -195,3 +194,60 @@ def test_deterministic_flag_with_the_rows_mode(gpu, kind):
     np.testing.assert_array_equal(runs[0][2], runs[1][2])
     sa = _capi.solve(_capi.Arrays.from_dict(p), loss="huber", f_scale=1.0, max_iter=25, linear_solver="pcg", pcg_tol=1e-10, schur_mode="chunks")
     assert abs(sa["final_cost"] - runs[0][0][-1]) <= 1e-8 * sa["final_cost"]
+
+
+def _landmarks_problem(n_cams, n_landmarks, seed=4):
+    """A street, plus landmarks seen by EVERY camera (tracks of n_cams > 256 observations: heavy points), one of them twice by
+    camera 5, two cameras fixed."""
+    p = dict(synthetic.make_street(n_cams, n_cams * 6, n_cams * 30, seed=seed, outlier_frac=0.02))
+    rng = np.random.default_rng(seed)
+    n0 = len(p["points"])
+    # (the street's cameras sit at (i, 0, 0) and look down +z: far ahead of the middle of the street is in front of all of them)
+    lm = np.stack([0.5 * n_cams + rng.uniform(-5.0, 5.0, n_landmarks), rng.uniform(-3.0, 3.0, n_landmarks),
+                   rng.uniform(8.0, 12.0, n_landmarks) * n_cams], axis=1)
+    p["points"] = np.concatenate([p["points"], lm])
+    cams = np.tile(np.arange(n_cams, dtype=np.int32), n_landmarks)
+    pts = np.repeat(np.arange(n0, n0 + n_landmarks, dtype=np.int32), n_cams)
+    cams = np.concatenate([cams, [5]]).astype(np.int32)
+    pts = np.concatenate([pts, [n0]]).astype(np.int32)
+    xy = synthetic.project_points(p["cam_pose"], p["cam_intr"], p["points"], cams, pts) + rng.normal(0.0, 0.5, (len(cams), 2))
+    perm = rng.permutation(len(p["obs_cam"]) + len(cams))      # (the caller's order is arbitrary)
+    p["obs_cam"] = np.concatenate([p["obs_cam"], cams])[perm]
+    p["obs_pt"] = np.concatenate([p["obs_pt"], pts])[perm]
+    p["obs_xy"] = np.concatenate([p["obs_xy"], xy])[perm]
+    p["cam_fixed"] = np.zeros(n_cams, np.uint8)
+    p["cam_fixed"][[0, 7]] = 1
+    return p
+
+
+@pytest.mark.parametrize("mode", ["chunks", "rows"])
+@pytest.mark.parametrize("loss", ["huber", "cauchy"])
+def test_heavy_points_through_the_entry_lists(gpu, mode, loss):
+    """Landmarks seen by all 300 cameras next to ordinary street tracks.  In the chunk mode the chunks go through k_build and the
+    landmarks' pairs are ADDED from the global lists (k_lin_heavy, k_rows_diag / k_rows_cross); in the rows mode they sit in the
+    lists with everybody else.  Same reduced system as the oracle's either way."""
+    p = _landmarks_problem(300, 4)
+    lam = 1e-3
+    a = _capi.analyze(_capi.Arrays.from_dict(p))
+    assert a["n_heavy_points"] == 4 and a["max_track"] == 301
+    nb = O.normal_blocks(*oracle_args(p), p["obs_xy"], 1.0, loss, floor=1.0)
+    S, gred, _, _, _ = O.reduced_system(nb, p["cam_fixed"], p["obs_cam"], p["obs_pt"], lam)
+    free = p["cam_fixed"] == 0
+    with _capi.Handle(_capi.Arrays.from_dict(p), loss=loss, f_scale=1.0, schur_mode=mode) as h:
+        h.build(lam)
+        r = h.reduced_system()
+        assert rel(r["U"][free], nb["U"][free]) < 1e-12 and rel(r["gc"][free], nb["gc"][free]) < 1e-11
+        assert rel(r["V"], nb["V"]) < 1e-11 and rel(r["gp"], nb["gp"]) < 1e-11
+        assert rel(r["S"], S) < 1e-9 and rel(r["gred"], gred) < 1e-9
+        assert abs(h.cost() - nb["F"]) <= 1e-12 * nb["F"]
+
+
+def test_heavy_points_cost_what_their_pairs_cost(gpu):
+    """Five landmarks seen by all 1 778 cameras of a street: 5 x 1.6 M pairs.  One workgroup per landmark with atomics took
+    100 ms per build pass; through the entry lists the pass stays within a few milliseconds."""
+    p = _landmarks_problem(1778, 5)
+    arr = _capi.Arrays.from_dict(p)
+    with _capi.Handle(arr, loss="huber", f_scale=1.0) as h:
+        ms, _ = h.build_bench(1e-3, warmup=1, reps=5)
+    print("street1778 + 5 landmarks: build pass %.3f ms" % ms)
+    assert ms < 10.0

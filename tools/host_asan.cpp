@@ -56,21 +56,32 @@ int main(int argc, char **argv) {
         const int e = ba_analyze(&P, &A);
         if (e == BA_OK) ++analyses; else ++rejected;
         if (e == BA_OK) {
-            // the rows mode of the analysis (global per-block entry lists): every entry inside its block, blocks ascending
-            ba::Symbolic s;
-            const char *msg = "";
-            if (ba::analyze_structure(nc, np, (int64_t)oc.size(), fixed.data(), oc.data(), op.data(), s, &msg, false, true) != BA_OK) { fprintf(stderr, "rows analysis refused: %s\n", msg); return 1; }
-            ba::finalize_pattern(s, {});
-            if (s.rw_ptr.size() != s.raw_keys.size() + 1 || (int64_t)s.rw_ent.size() != 2 * s.rw_ptr.back()) { fprintf(stderr, "rows tables: sizes\n"); return 1; }
-            for (size_t k = 0; k < s.raw_keys.size(); ++k) {
-                if (k && s.raw_keys[k] <= s.raw_keys[k - 1]) { fprintf(stderr, "rows tables: keys not ascending\n"); return 1; }
-                if (s.rw_ptr[k + 1] <= s.rw_ptr[k]) { fprintf(stderr, "rows tables: empty block\n"); return 1; }
-                const int fi = (int)(s.raw_keys[k] >> 32), fj = (int)(s.raw_keys[k] & 0xffffffff);
-                if (s.upper_keys[s.ck_pair_slot[k]] != s.raw_keys[k]) { fprintf(stderr, "rows tables: slot\n"); return 1; }
-                for (int64_t q = s.rw_ptr[k]; q < s.rw_ptr[k + 1]; ++q) {
-                    const int32_t oi = s.rw_ent[2 * q], oj = s.rw_ent[2 * q + 1];
-                    if (oi < 0 || oj < 0 || oi >= (int64_t)oc.size() || oj >= (int64_t)oc.size() || s.o_pt[oi] != s.o_pt[oj] ||
-                        s.cam_free[s.o_cam[oi]] != fi || s.cam_free[s.o_cam[oj]] != fj) { fprintf(stderr, "rows tables: entry\n"); return 1; }
+            // the global per-block entry lists of the analysis (rows mode: every point; chunk mode: the heavy points only):
+            // every entry inside its block, blocks ascending, slots resolved
+            for (int rows = 0; rows < 2; ++rows) {
+                ba::Symbolic s;
+                const char *msg = "";
+                if (ba::analyze_structure(nc, np, (int64_t)oc.size(), fixed.data(), oc.data(), op.data(), s, &msg, false, rows != 0) != BA_OK) { fprintf(stderr, "rows analysis refused: %s\n", msg); return 1; }
+                ba::finalize_pattern(s, {});
+                if (s.rw_keys.empty() && s.rw_ptr.empty()) continue;   // (chunk mode without heavy points)
+                if (s.rw_ptr.size() != s.rw_keys.size() + 1 || s.rw_slot.size() != s.rw_keys.size() || (int64_t)s.rw_ent.size() != 2 * s.rw_ptr.back()) { fprintf(stderr, "rows tables: sizes\n"); return 1; }
+                int64_t want = 0;   // entries the lists must hold: pairs (a <= c) of free observations of the covered points
+                for (int64_t o = 0; o < (int64_t)oc.size(); ++o) {
+                    if (s.cam_free[s.o_cam[o]] < 0 || (!rows && s.o_pt[o] < s.n_pts_chunked)) continue;
+                    for (int64_t o2 = o; o2 < (int64_t)oc.size() && s.o_pt[o2] == s.o_pt[o]; ++o2)
+                        if (s.cam_free[s.o_cam[o2]] >= 0) want += (o2 != o && s.o_cam[o2] == s.o_cam[o]) ? 2 : 1;
+                }
+                if (want != s.rw_ptr.back()) { fprintf(stderr, "rows tables: %lld entries, expected %lld\n", (long long)s.rw_ptr.back(), (long long)want); return 1; }
+                for (size_t k = 0; k < s.rw_keys.size(); ++k) {
+                    if (k && s.rw_keys[k] <= s.rw_keys[k - 1]) { fprintf(stderr, "rows tables: keys not ascending\n"); return 1; }
+                    if (s.rw_ptr[k + 1] <= s.rw_ptr[k]) { fprintf(stderr, "rows tables: empty block\n"); return 1; }
+                    const int fi = (int)(s.rw_keys[k] >> 32), fj = (int)(s.rw_keys[k] & 0xffffffff);
+                    if (s.upper_keys[s.rw_slot[k]] != s.rw_keys[k]) { fprintf(stderr, "rows tables: slot\n"); return 1; }
+                    for (int64_t q = s.rw_ptr[k]; q < s.rw_ptr[k + 1]; ++q) {
+                        const int32_t oi = s.rw_ent[2 * q], oj = s.rw_ent[2 * q + 1];
+                        if (oi < 0 || oj < 0 || oi >= (int64_t)oc.size() || oj >= (int64_t)oc.size() || s.o_pt[oi] != s.o_pt[oj] ||
+                            s.cam_free[s.o_cam[oi]] != fi || s.cam_free[s.o_cam[oj]] != fj || (!rows && s.o_pt[oi] < s.n_pts_chunked)) { fprintf(stderr, "rows tables: entry\n"); return 1; }
+                    }
                 }
             }
             ++rows_analyses;
