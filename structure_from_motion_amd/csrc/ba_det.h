@@ -263,12 +263,12 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build_det(const BuildArgs A, cons
                 const bool real = ent != PAIR_NULL;
                 double Tj[9], Yj[3], Yi[3];
 #pragma unroll
-                for (int k = 0; k < 9; ++k) Tj[k] = tj[k];
+                for (int k = 0; k < 9; ++k) Tj[k] = lds_f64(tj + k);   // (single 8-byte reads: lds_f64, ba_device.h)
 #pragma unroll
-                for (int k = 0; k < 3; ++k) { Yj[k] = tj[9 + k]; Yi[k] = ti[9 + k]; }
+                for (int k = 0; k < 3; ++k) { Yj[k] = lds_f64(tj + 9 + k); Yi[k] = lds_f64(ti + 9 + k); }
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
-                    const double a0 = ti[3 * r], a1 = ti[3 * r + 1], a2 = ti[3 * r + 2];
+                    const double a0 = lds_f64(ti + 3 * r), a1 = lds_f64(ti + 3 * r + 1), a2 = lds_f64(ti + 3 * r + 2);
                     if (real) {
                         double B[6];
                         B[3] = a0 * Tj[0] + a1 * Tj[1] + a2 * Tj[2];

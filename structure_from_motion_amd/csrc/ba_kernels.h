@@ -292,9 +292,10 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
     if (tid < npts) {
         double *vp = &sP[tid * 9];
         const double *rp = &sT[P_REP_BASE + tid * 9];
-        const double v00 = vp[0] + rp[0], v01 = vp[1] + rp[1], v02 = vp[2] + rp[2], v11 = vp[3] + rp[3], v12 = vp[4] + rp[4],
-                     v22 = vp[5] + rp[5];
-        const double g0 = vp[6] + rp[6], g1 = vp[7] + rp[7], g2 = vp[8] + rp[8];
+        // (single 8-byte reads, here and below: lds_f64, ba_device.h)
+        const double v00 = lds_f64(vp) + lds_f64(rp), v01 = lds_f64(vp + 1) + lds_f64(rp + 1), v02 = lds_f64(vp + 2) + lds_f64(rp + 2),
+                     v11 = lds_f64(vp + 3) + lds_f64(rp + 3), v12 = lds_f64(vp + 4) + lds_f64(rp + 4), v22 = lds_f64(vp + 5) + lds_f64(rp + 5);
+        const double g0 = lds_f64(vp + 6) + lds_f64(rp + 6), g1 = lds_f64(vp + 7) + lds_f64(rp + 7), g2 = lds_f64(vp + 8) + lds_f64(rp + 8);
         gmax_loc = fmax(fabs(g0), fmax(fabs(g1), fabs(g2)));
         if (A.dbg_v) {
             double *dv = &A.dbg_v[(size_t)(pb + tid) * 6];
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
     // ---- phase 2b: T' = Wt L^-T and Y into LDS (overwrites the phase-1 staging) ---------------------------
     if (act && lc != -2) {
         const double *vp = &sP[lp * 9];
-        const double i00 = vp[0], i10 = vp[1], i11 = vp[2], i20 = vp[3], i21 = vp[4], i22 = vp[5];
+        const double i00 = lds_f64(vp), i10 = lds_f64(vp + 1), i11 = lds_f64(vp + 2), i20 = lds_f64(vp + 3), i21 = lds_f64(vp + 4), i22 = lds_f64(vp + 5);
         double *tp = &sT[tid * T_STRIDE];
         double t[9];
 #pragma unroll
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
         for (int k = 0; k < 9; ++k) tp[k] = t[k];
         tp[9] = Yr[0]; tp[10] = Yr[1]; tp[11] = Yr[2];
         if (lc == -1 || lc >= CHUNK_CAMS) {  // camera without a tile: its part of the reduced gradient, -T u = -[Y x w; w], w = T' u
-            const double u0 = vp[6], u1 = vp[7], u2 = vp[8];
+            const double u0 = lds_f64(vp + 6), u1 = lds_f64(vp + 7), u2 = lds_f64(vp + 8);
             const double w0 = t[0] * u0 + t[1] * u1 + t[2] * u2, w1 = t[3] * u0 + t[4] * u1 + t[5] * u2,
                          w2 = t[6] * u0 + t[7] * u1 + t[8] * u2;
             double *d = &A.gred[(size_t)fcam * 6];
@@ -396,19 +397,19 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
 #pragma unroll
             for (int e = 0; e < PAIR_RUN / 2; ++e) {
                 const unsigned ent = en[e];
-                const unsigned ec = ent == PAIR_NULL ? 0u : ent;  // a null entry reads observation 0: harmless
+                const unsigned ec = ent == PAIR_NULL ? 0u : ent;
                 const int oi = ec & 255u, oj = (ec >> 8) & 255u;
                 const double *ti = &sT[oi * T_STRIDE], *tj = &sT[oj * T_STRIDE], *uu = &sP[(int)sLp[oi] * 9 + 6];
                 const bool real = ent != PAIR_NULL, self = real && oi == oj;
                 if (self) self_lc = sLc[oi];
                 double Tj[9], Yj[3], Yi[3], tu[3];
 #pragma unroll
-                for (int k = 0; k < 9; ++k) Tj[k] = tj[k];
+                for (int k = 0; k < 9; ++k) Tj[k] = lds_f64(tj + k);
 #pragma unroll
-                for (int k = 0; k < 3; ++k) { Yj[k] = tj[9 + k]; Yi[k] = ti[9 + k]; tu[k] = uu[k]; }
+                for (int k = 0; k < 3; ++k) { Yj[k] = lds_f64(tj + 9 + k); Yi[k] = lds_f64(ti + 9 + k); tu[k] = lds_f64(uu + k); }
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
-                    const double a0 = ti[3 * r], a1 = ti[3 * r + 1], a2 = ti[3 * r + 2];
+                    const double a0 = lds_f64(ti + 3 * r), a1 = lds_f64(ti + 3 * r + 1), a2 = lds_f64(ti + 3 * r + 2);
                     if (real) {
                         double B[6];
                         B[3] = a0 * Tj[0] + a1 * Tj[1] + a2 * Tj[2];
@@ -479,6 +480,7 @@ __global__ __launch_bounds__(CHUNK_OBS) __attribute__((amdgpu_waves_per_eu(3, 3)
             }
         }
         lds_barrier();  // every lane is done reading T
+        // (the lane pairs take the groups window by window; the flush wants the groups of a pair side by side: ck_park)
         double *park = &sT[(tid >> 1) * 36];
         if (half == 0) {
 #pragma unroll

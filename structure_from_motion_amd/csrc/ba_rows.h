@@ -109,7 +109,7 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_lin(const BuildArgs A, double *__
         for (int k = 0; k < 9; ++k) a[k] = 0.0;
         for (int o = sStart[tid], o1 = sStart[tid + 1]; o < o1; ++o) {
 #pragma unroll
-            for (int k = 0; k < 9; ++k) a[k] += sV[o * 9 + k];
+            for (int k = 0; k < 9; ++k) a[k] += lds_f64(&sV[o * 9 + k]);
         }
         const double v00 = a[0], v01 = a[1], v02 = a[2], v11 = a[3], v12 = a[4], v22 = a[5];
         const double g0 = a[6], g1 = a[7], g2 = a[8];

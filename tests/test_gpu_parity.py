@@ -555,7 +555,7 @@ def test_append_extends_the_resident_structure(gpu):
                 fresh.set_values(_capi.Arrays.from_dict(p))
                 s1, s2 = h.run(), fresh.run()
                 assert s1["status"] == s2["status"] and s1["iterations"] == s2["iterations"]
-                assert s1["initial_cost"] == s2["initial_cost"]
+                assert abs(s1["initial_cost"] - s2["initial_cost"]) <= 1e-14 * s2["initial_cost"]   # (other chunks, another order of the sum)
                 assert abs(s1["final_cost"] - s2["final_cost"]) <= 1e-9 * s2["final_cost"]
                 np.testing.assert_allclose(h.state()[0], fresh.state()[0], rtol=1e-6, atol=1e-8)
                 np.testing.assert_allclose(h.state()[1], fresh.state()[1], rtol=1e-5, atol=1e-7)
@@ -636,7 +636,7 @@ def test_append_replans_the_cyclic_reduction(gpu):
         s1, s2, s3 = h.run(), fresh.run(), dense.run()
         assert s1["pcg_iterations"] == 0 and s2["pcg_iterations"] == 0
         assert s1["status"] == s2["status"] == s3["status"] and s1["iterations"] == s2["iterations"] == s3["iterations"]
-        assert s1["initial_cost"] == s2["initial_cost"]
+        assert abs(s1["initial_cost"] - s2["initial_cost"]) <= 1e-14 * s2["initial_cost"]   # (other chunks, another order of the sum)
         assert abs(s1["final_cost"] - s2["final_cost"]) <= 1e-9 * s2["final_cost"]
         assert abs(s1["final_cost"] - s3["final_cost"]) <= 1e-8 * s3["final_cost"]
         np.testing.assert_allclose(h.state()[0], fresh.state()[0], rtol=1e-6, atol=1e-8)
