@@ -103,7 +103,7 @@ __global__ __launch_bounds__(BA_DENSE_THREADS) void k_dense_cholesky_solve(int n
         band_wave_sync();
         int bad = 0;
         // Two 16x16 tiles (the tile chain of the cyclic reduction, ba_bcr.h): tile (0,0) factored and its factor inverted
-        // in registers, a row per lane, the pivot column's entries broadcast by readlane (bcr_potrf16); tile (1,0) <- (1,0)
+        // in registers, a row per lane, the pivot column's entries broadcast as DPP operands (bcr_potrf16); tile (1,0) <- (1,0)
         // Linv^T and (1,1) -= (1,0) (1,0)^T on the matrix core; then tile (1,1).  13 k cycles per block -- the version
         // before worked in LDS, four columns per step with every lane factoring the 4x4 pivot block redundantly: 31 k.
         {

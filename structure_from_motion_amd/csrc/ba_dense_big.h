@@ -70,7 +70,7 @@ __global__ void k_big_init(int n, int M, const double *__restrict__ g, double *_
 
 // Cholesky of the 64 x 64 diagonal block at k0 and the inverse of its factor: ONE workgroup of four waves, the block in
 // LDS, factored right-looking in 16-column steps the way k_bcr_factor does it (ba_bcr.h) -- wave 0 owns the serial chain
-// (bcr_potrf16: the 16 x 16 diagonal tile and the inverse of its factor in registers, readlane broadcasts), then its own
+// (bcr_potrf16: the 16 x 16 diagonal tile and the inverse of its factor in registers, DPP row broadcasts), then its own
 // panel tile (s+1, s) and the update of tile (s+1, s+1), and is already factoring the next diagonal tile while waves
 // 1..3 apply step s to the rest (panel tiles = products with the tile's inverse, trailing tiles, all MFMA).  The inverse
 // X = L^-1 of the whole block follows tile by tile, by distance from the diagonal:

@@ -116,7 +116,18 @@ def create_sharded_handle(shard, rank, world, group=None, stream_ordered=True, f
         if native is None:
             native = dist.get_backend(group) == "nccl"
         if native:
-            box = [_capi.rccl_unique_id() if rank == 0 else None]
+            # (every rank must take the same transport: the ranks first agree that the RCCL binding can be had at all)
+            try:
+                uid, err = _capi.rccl_unique_id(), None
+            except Exception as e:   # librccl.so not loadable on this rank
+                uid, err = None, str(e)
+            errs = [e for e in gather(err) if e]
+            if errs:
+                import warnings
+                warnings.warn("RCCL binding unavailable (%s): collectives through torch.distributed instead" % errs[0])
+                native = False
+        if native:
+            box = [uid if rank == 0 else None]
             # (`rank` is the rank inside `group`; torch's `src` is a global rank)
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
             h.rccl_init(box[0], rank, world)
