@@ -45,6 +45,7 @@
 #include <vector>
 
 #include "ba_banded.h"  // band_readlane, band_rsqrt, band_wave_sync
+#include "ba_device.h"  // lds_f64
 #include "ba_device.h"  // wave_sum_dpp
 #include "ba_dense.h"   // mfma_d4
 #include "ba_tile16.h" // bcr_potrf16
@@ -586,7 +587,7 @@ __global__ __launch_bounds__(64 * (NT + BA_BCR_DWAVES)) void k_bcr_factor(const 
         mfma_d4 w = mfma_d4{0.0, 0.0, 0.0, 0.0};
         double aq[4], bq[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { aq[q] = sD[arow * LDD + 16 * s + 4 * q + l4]; bq[q] = sLinv[l15 * 17 + 4 * q + l4]; }
+        for (int q = 0; q < 4; ++q) { aq[q] = lds_f64(&sD[arow * LDD + 16 * s + 4 * q + l4]); bq[q] = lds_f64(&sLinv[l15 * 17 + 4 * q + l4]); }
 #pragma unroll
         for (int q = 0; q < 4; ++q) w = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[q], bq[q], w, 0, 0, 0);
         if (i < NT) {
@@ -601,8 +602,8 @@ __global__ __launch_bounds__(64 * (NT + BA_BCR_DWAVES)) void k_bcr_factor(const 
         double aq[4], bq[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            aq[q] = -sD[arow * LDD + 16 * s + 4 * q + l4];
-            bq[q] = sD[(16 * j + l15) * LDD + 16 * s + 4 * q + l4];
+            aq[q] = -lds_f64(&sD[arow * LDD + 16 * s + 4 * q + l4]);
+            bq[q] = lds_f64(&sD[(16 * j + l15) * LDD + 16 * s + 4 * q + l4]);
         }
         mfma_d4 w;
         if (i < NT) {
@@ -657,17 +658,17 @@ __global__ __launch_bounds__(64 * (NT + BA_BCR_DWAVES)) void k_bcr_factor(const 
                 band_wave_sync();
                 double aq[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) aq[q] = stg[l15 * 17 + 4 * q + l4];
+                for (int q = 0; q < 4; ++q) aq[q] = lds_f64(&stg[l15 * 17 + 4 * q + l4]);
                 mfma_d4 w = mfma_d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) w = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[q], sLinv[l15 * 17 + 4 * q + l4], w, 0, 0, 0);
+                for (int q = 0; q < 4; ++q) w = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[q], lds_f64(&sLinv[l15 * 17 + 4 * q + l4]), w, 0, 0, 0);
                 acc[s] = w;
                 band_wave_sync();
 #pragma unroll
                 for (int v = 0; v < 4; ++v) stg[(l4 + 4 * v) * 17 + l15] = w[v];
                 band_wave_sync();
 #pragma unroll
-                for (int q = 0; q < 4; ++q) aW[q] = -stg[l15 * 17 + 4 * q + l4];
+                for (int q = 0; q < 4; ++q) aW[q] = -lds_f64(&stg[l15 * 17 + 4 * q + l4]);
             }
             BCR_STAMP(4 + 4 * s);
             __syncthreads();
@@ -689,7 +690,7 @@ __global__ __launch_bounds__(64 * (NT + BA_BCR_DWAVES)) void k_bcr_factor(const 
                     for (int c = s + 1; c < NT; ++c)
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(aW[q], sD[(16 * c + l15) * LDD + 16 * s + 4 * q + l4], acc[c], 0, 0, 0);
+                            acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(aW[q], lds_f64(&sD[(16 * c + l15) * LDD + 16 * s + 4 * q + l4]), acc[c], 0, 0, 0);
                 }
             }
         });
