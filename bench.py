@@ -264,6 +264,26 @@ def other_configs(_capi, synthetic):
         h.build_bench(1e-4, warmup=0, reps=3)
         orbit["build_ms_chunk_kernel_forced"], _ = h.build_bench(1e-4, warmup=0, reps=10)
     out["orbit1024"] = orbit
+    # Landmarks: a street of 1778 cameras (1 M observations) plus five points seen by EVERY camera -- tracks no chunk holds
+    # ("heavy points": rows from k_lin_heavy, 7.9 M pairs through the global entry lists of csrc/ba_rows.h)
+    nc, k = 1778, 5
+    p = synthetic.make_street(nc, 200000, 1000000, seed=3)
+    rng = np.random.default_rng(1)
+    n0 = len(p["points"])
+    lm = np.stack([0.5 * nc + rng.uniform(-5, 5, k), rng.uniform(-3, 3, k), rng.uniform(8, 12, k) * nc], axis=1)   # far ahead of the street
+    q = dict(p)
+    q["points"] = np.vstack([p["points"], lm])
+    oc = np.tile(np.arange(nc, dtype=np.int32), k)
+    op = np.repeat(np.arange(n0, n0 + k, dtype=np.int32), nc)
+    xy = synthetic.project_points(p["cam_pose"], p["cam_intr"], q["points"], oc, op) + rng.normal(0, 0.5, (len(oc), 2))
+    q["obs_cam"] = np.concatenate([p["obs_cam"], oc]); q["obs_pt"] = np.concatenate([p["obs_pt"], op]); q["obs_xy"] = np.vstack([p["obs_xy"], xy])
+    lmk = {"cameras": nc, "landmarks": k, "landmark_pairs": k * nc * (nc + 1) // 2}
+    for tag, prob in (("street", p), ("street_plus_landmarks", q)):
+        with _capi.Handle(_capi.Arrays.from_dict(prob), loss="huber", f_scale=1.0) as h:
+            h.build_bench(1e-4, warmup=0, reps=2)
+            ms, _ = h.build_bench(1e-4, warmup=0, reps=5)
+        lmk[tag] = {"observations": len(prob["obs_cam"]), "build_ms": ms}
+    out["street1778_landmarks"] = lmk
     return out
 
 
