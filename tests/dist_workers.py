@@ -31,6 +31,10 @@ def _engine_problem():
         # unstructured co-visibility (the rows mode of the build pass when BA_TEST_SCHUR=rows)
         return synthetic.make_ring(60, 2500, seed=31, K=(1200.0, 1200.0, 960.0, 540.0), focal_jitter=0.05, noise=0.5, outlier_frac=0.02,
                                    visibility="random", mean_track=6.0, max_track=16, n_fixed=2, radius=6.0), 300
+    if os.environ.get("BA_TEST_PROBLEM") == "landmarks270":
+        # landmarks seen by every camera (tracks no chunk holds: heavy points, their pairs through the global entry lists)
+        return synthetic.make_ring(270, 110, seed=3, mean_track=30.0, max_track=60, n_landmarks=3, outlier_frac=0.05, n_fixed=2,
+                                   n_unobserved=2), 40
     return synthetic.make_ring(16, 600, seed=8, mean_track=4.0, outlier_frac=0.02), 80
 
 

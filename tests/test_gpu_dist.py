@@ -86,6 +86,25 @@ def test_two_ranks_in_the_rows_mode(gpu, tmp_path, monkeypatch):
     assert np.allclose(r0["cp"], arr.cam_pose, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("mode", ["chunks", "rows"])
+def test_two_ranks_with_heavy_points(gpu, tmp_path, monkeypatch, mode):
+    """Landmarks seen by all 270 cameras (heavy points: rows from k_lin_heavy, pairs through the global entry lists -- added behind
+    the chunk kernel in the chunk mode) on two point shards: the rank that owns a landmark contributes its blocks, the all-reduce
+    adds the shards up; against the single handle."""
+    monkeypatch.setenv("BA_TEST_PROBLEM", "landmarks270")
+    monkeypatch.setenv("BA_TEST_SCHUR", mode)
+    p = synthetic.make_ring(270, 110, seed=3, mean_track=30.0, max_track=60, n_landmarks=3, outlier_frac=0.05, n_fixed=2, n_unobserved=2)
+    arr = _capi.Arrays.from_dict(p)
+    assert _capi.analyze(arr)["n_heavy_points"] == 3
+    s = _capi.solve(arr, loss="huber", f_scale=1.0, max_iter=40, schur_mode=mode)
+    mp.spawn(engine_sharded_solve, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert int(r0["status"]) == int(r1["status"]) == s["status"]
+    np.testing.assert_array_equal(r0["cp"], r1["cp"])
+    assert abs(float(r0["cost"]) - s["final_cost"]) <= 1e-7 * s["final_cost"]
+    assert np.allclose(r0["cp"], arr.cam_pose, rtol=1e-5, atol=1e-5)
+
+
 def test_rank_without_observations_stays_in_step(gpu, tmp_path):
     mp.spawn(engine_sharded_empty_rank, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     r0, r1 = np.load(tmp_path / "empty0.npz"), np.load(tmp_path / "empty1.npz")
