@@ -561,8 +561,9 @@ int do_build(BaHandle *h, bool timed) {
         hipLaunchKernelGGL(k_build_heavy, dim3(h->n_heavy), dim3(256), 0, st, build_args(h), heavy_args(h), det_args(h));
     } else if (h->n_heavy > 0 && !h->sym.rows) {
         // chunk mode: the lists hold the heavy points only; their blocks are ADDED behind k_build (one owner per block)
+        // (no table at all when every observation of the heavy points belongs to a fixed camera)
         lin_heavy();
-        if (nf > 0) hipLaunchKernelGGL((k_rows_diag<true>), dim3(nf), dim3(256), 0, st, R, h->S, h->U, h->gc, h->gred);
+        if (nf > 0 && h->rw_rows > 0) hipLaunchKernelGGL((k_rows_diag<true>), dim3(nf), dim3(256), 0, st, R, h->S, h->U, h->gc, h->gred);
         if (h->rw_nx > 0) hipLaunchKernelGGL((k_rows_cross<true>), dim3((h->rw_nx + 127) / 128), dim3(256), 0, st, R, h->S);
     }
     if (det) {

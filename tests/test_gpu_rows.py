@@ -251,3 +251,33 @@ def test_heavy_points_cost_what_their_pairs_cost(gpu):
         ms, _ = h.build_bench(1e-3, warmup=1, reps=5)
     print("street1778 + 5 landmarks: build pass %.3f ms" % ms)
     assert ms < 10.0
+
+
+@pytest.mark.parametrize("mode", ["chunks", "rows"])
+def test_heavy_points_seen_by_fixed_cameras_only(gpu, mode):
+    """A landmark whose every observation belongs to a FIXED camera gives the reduced system nothing (no pair, no camera block):
+    in the chunk mode there is then no entry table at all -- only the point's own block and its cost."""
+    p = dict(synthetic.make_street(300, 1800, 9000, seed=6, outlier_frac=0.02))
+    rng = np.random.default_rng(6)
+    n0 = len(p["points"])
+    p["points"] = np.concatenate([p["points"], [[150.0, 1.0, 3000.0]]])
+    cams = np.arange(270, dtype=np.int32)                       # the landmark: cameras 0 .. 269, all of them fixed below
+    pts = np.full(270, n0, np.int32)
+    xy = synthetic.project_points(p["cam_pose"], p["cam_intr"], p["points"], cams, pts) + rng.normal(0.0, 0.5, (270, 2))
+    p["obs_cam"] = np.concatenate([p["obs_cam"], cams]); p["obs_pt"] = np.concatenate([p["obs_pt"], pts]); p["obs_xy"] = np.concatenate([p["obs_xy"], xy])
+    p["cam_fixed"] = np.ones(300, np.uint8)
+    p["cam_fixed"][270:] = 0
+    lam = 1e-3
+    assert _capi.analyze(_capi.Arrays.from_dict(p))["n_heavy_points"] == 1
+    nb = O.normal_blocks(*oracle_args(p), p["obs_xy"], 1.0, "huber", floor=1.0)
+    S, gred, _, _, _ = O.reduced_system(nb, p["cam_fixed"], p["obs_cam"], p["obs_pt"], lam)
+    free = p["cam_fixed"] == 0
+    with _capi.Handle(_capi.Arrays.from_dict(p), loss="huber", f_scale=1.0, schur_mode=mode) as h:
+        h.build(lam)
+        r = h.reduced_system()
+        assert rel(r["U"][free], nb["U"][free]) < 1e-12 and rel(r["gc"][free], nb["gc"][free]) < 1e-11
+        assert rel(r["V"], nb["V"]) < 1e-11 and rel(r["gp"], nb["gp"]) < 1e-11
+        assert rel(r["S"], S) < 1e-9 and rel(r["gred"], gred) < 1e-9
+        assert abs(h.cost() - nb["F"]) <= 1e-12 * nb["F"]
+        s = h.run(5)
+        assert s["final_cost"] < s["initial_cost"]
