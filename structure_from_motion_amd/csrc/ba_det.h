@@ -117,7 +117,7 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build_det(const BuildArgs A, cons
         const int o1 = sStart[tid + 1];
         for (int o = sStart[tid]; o < o1; ++o) {
 #pragma unroll
-            for (int k = 0; k < 9; ++k) v[k] += sT[o * 9 + k];
+            for (int k = 0; k < 9; ++k) v[k] += lds_f64(&sT[o * 9 + k]);
         }
         const double v00 = v[0], v01 = v[1], v02 = v[2], v11 = v[3], v12 = v[4], v22 = v[5];
         const double g0 = v[6], g1 = v[7], g2 = v[8];
@@ -179,10 +179,14 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build_det(const BuildArgs A, cons
             const int o = w * 64 + __builtin_ctzll(m);
             m &= m - 1;
             const double *c = &sT[o * DET_CS];
-            const double a0 = c[12] * c[row], a1 = c[13] * c[6 + row];
+            double cc[16];   // (single 8-byte reads: the row stride is odd, lds_f64, ba_device.h)
 #pragma unroll
-            for (int j = 0; j < 6; ++j) acc[j] += a0 * c[j] + a1 * c[6 + j];
-            g += c[row] * c[14] + c[6 + row] * c[15];
+            for (int k = 0; k < 16; ++k) cc[k] = lds_f64(c + k);
+            const double cr0 = lds_f64(c + row), cr1 = lds_f64(c + 6 + row);
+            const double a0 = cc[12] * cr0, a1 = cc[13] * cr1;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) acc[j] += a0 * cc[j] + a1 * cc[6 + j];
+            g += cr0 * cc[14] + cr1 * cc[15];
         }
 #pragma unroll
         for (int j = 0; j < 6; ++j) { acc[j] += dpp_f64<0xB1>(acc[j]); acc[j] += dpp_f64<0x4E>(acc[j]); }
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build_det(const BuildArgs A, cons
     // ---- phase 2b: T' = Wt L^-T and Y into LDS ----------------------------------------------------------------------
     if (act && lc >= 0) {
         const double *vp = &sP[lp * 9];
-        const double i00 = vp[0], i10 = vp[1], i11 = vp[2], i20 = vp[3], i21 = vp[4], i22 = vp[5];
+        const double i00 = lds_f64(vp), i10 = lds_f64(vp + 1), i11 = lds_f64(vp + 2), i20 = lds_f64(vp + 3), i21 = lds_f64(vp + 4), i22 = lds_f64(vp + 5);
         double *tp = &sT[tid * T_STRIDE];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -225,9 +229,14 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_build_det(const BuildArgs A, cons
             const int o = w * 64 + __builtin_ctzll(m);
             m &= m - 1;
             const double *t = &sT[o * T_STRIDE], *u = &sP[(int)sLp[o] * 9 + 6];
-            const double w0 = t[0] * u[0] + t[1] * u[1] + t[2] * u[2], w1 = t[3] * u[0] + t[4] * u[1] + t[5] * u[2],
-                         w2 = t[6] * u[0] + t[7] * u[1] + t[8] * u[2];
-            const double y0 = t[9], y1 = t[10], y2 = t[11];
+            double tt[12], uu[3];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) tt[k] = lds_f64(t + k);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) uu[k] = lds_f64(u + k);
+            const double w0 = tt[0] * uu[0] + tt[1] * uu[1] + tt[2] * uu[2], w1 = tt[3] * uu[0] + tt[4] * uu[1] + tt[5] * uu[2],
+                         w2 = tt[6] * uu[0] + tt[7] * uu[1] + tt[8] * uu[2];
+            const double y0 = tt[9], y1 = tt[10], y2 = tt[11];
             g[0] += -(y1 * w2 - y2 * w1);
             g[1] += -(y2 * w0 - y0 * w2);
             g[2] += -(y0 * w1 - y1 * w0);
