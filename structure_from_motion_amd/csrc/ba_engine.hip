@@ -542,8 +542,11 @@ int do_build(BaHandle *h, bool timed) {
             else hipLaunchKernelGGL((k_lin<-1>), dim3(h->n_chunks), dim3(CHUNK_OBS), 0, st, build_args(h), R.rows, R.tails);
         }
         if (h->n_heavy > 0) lin_heavy();
-        if (nf > 0 && h->n_chunks + h->n_heavy > 0) hipLaunchKernelGGL((k_rows_diag<false>), dim3(nf), dim3(256), 0, st, R, h->S, h->U, h->gc, h->gred);
-        if (h->rw_nx > 0) hipLaunchKernelGGL((k_rows_cross<false>), dim3((h->rw_nx + 127) / 128), dim3(256), 0, st, R, h->S);
+        {
+            const int n_diag = (nf > 0 && h->n_chunks + h->n_heavy > 0) ? nf : 0, n_cross = (h->rw_nx + 127) / 128;
+            if (n_diag + n_cross > 0)
+                hipLaunchKernelGGL((k_rows_schur<false>), dim3(n_diag + n_cross), dim3(256), 0, st, R, h->S, h->U, h->gc, h->gred, n_diag);
+        }
     } else if (h->n_chunks > 0) {
         BuildArgs A = build_args(h);
         if (h->stamps.n) {
@@ -563,8 +566,11 @@ int do_build(BaHandle *h, bool timed) {
         // chunk mode: the lists hold the heavy points only; their blocks are ADDED behind k_build (one owner per block)
         // (no table at all when every observation of the heavy points belongs to a fixed camera)
         lin_heavy();
-        if (nf > 0 && h->rw_rows > 0) hipLaunchKernelGGL((k_rows_diag<true>), dim3(nf), dim3(256), 0, st, R, h->S, h->U, h->gc, h->gred);
-        if (h->rw_nx > 0) hipLaunchKernelGGL((k_rows_cross<true>), dim3((h->rw_nx + 127) / 128), dim3(256), 0, st, R, h->S);
+        {
+            const int n_diag = (nf > 0 && h->rw_rows > 0) ? nf : 0, n_cross = (h->rw_nx + 127) / 128;
+            if (n_diag + n_cross > 0)
+                hipLaunchKernelGGL((k_rows_schur<true>), dim3(n_diag + n_cross), dim3(256), 0, st, R, h->S, h->U, h->gc, h->gred, n_diag);
+        }
     }
     if (det) {
         const long long n_el = (long long)h->n_upper * 36 + (long long)nf * 33;

@@ -15,6 +15,7 @@
 //     k_build's Schur phase does, and STORES the block -- every block is written once, by its owner, no atomics;
 //   * k_rows_diag: one workgroup per free camera: its observations (the entries of its diagonal block) give U, g_c, its part
 //     of the reduced gradient and the diagonal block, summed over the lanes in a fixed order.
+// (k_rows_diag and k_rows_cross are the two kinds of workgroup of ONE launch, k_rows_schur: they only depend on k_lin.)
 // Every floating-point sum of these three kernels has a fixed order (k_lin gathers each point's sums over its consecutive
 // lanes): without heavy points two passes over the same state give the same bits.
 // The host builds the lists once per structure (analyze_structure(..., rows); Symbolic::rw_ent / rw_ptr).  Heavy points (tracks
@@ -206,9 +207,9 @@ __device__ __forceinline__ void load_row12(const double *__restrict__ rows, long
 // ADD: the blocks are added to (chunk mode: the heavy points' pairs on top of what the chunk kernel accumulated; every
 // block still has ONE owner here, and the launch is ordered behind the chunk kernel: plain read-modify-write).
 template <bool ADD>
-__global__ __launch_bounds__(256) void k_rows_cross(const RowsArgs R, double *__restrict__ S) {
+__device__ __forceinline__ void rows_cross_block(const RowsArgs &R, double *__restrict__ S, const int blk) {
     const int tid = threadIdx.x, half = tid & 1;
-    const int g = blockIdx.x * 128 + (tid >> 1);
+    const int g = blk * 128 + (tid >> 1);
     const bool valid = g < R.n_x;
     const int key = R.xblk[valid ? g : 0];
     const long long e0 = R.ptr[key], e1 = valid ? R.ptr[key + 1] : e0;
@@ -248,10 +249,10 @@ __global__ __launch_bounds__(256) void k_rows_cross(const RowsArgs R, double *__
 // camera's U, g_c and its part of the reduced gradient -- and, for a camera that sees a point twice, the pairs (i, j), (j, i).
 constexpr int DIAG_VALS = 36 + 21 + 6 + 6;
 template <bool ADD>
-__global__ __launch_bounds__(256) void k_rows_diag(const RowsArgs R, double *__restrict__ S, double *__restrict__ U, double *__restrict__ gc,
-                                                   double *__restrict__ gred) {
+__device__ __forceinline__ void rows_diag_block(const RowsArgs &R, double *__restrict__ S, double *__restrict__ U, double *__restrict__ gc,
+                                                double *__restrict__ gred, const int f) {
     __shared__ double sW[4][DIAG_VALS];
-    const int f = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int key = R.diag_key[f];
     if (key < 0) return;   // (no observation outside the heavy points: the cleared accumulators stand)
     const long long e0 = R.ptr[key], e1 = R.ptr[key + 1];
@@ -312,6 +313,14 @@ __global__ __launch_bounds__(256) void k_rows_diag(const RowsArgs R, double *__r
         const double sv = (tid < 36 || tid >= 63) ? -v : v;
         *dst = ADD ? *dst + sv : sv;
     }
+}
+
+// Both in ONE launch (they only depend on k_lin): the first n_diag workgroups are the cameras', the rest the off-diagonal blocks'.
+template <bool ADD>
+__global__ __launch_bounds__(256) void k_rows_schur(const RowsArgs R, double *__restrict__ S, double *__restrict__ U, double *__restrict__ gc,
+                                                    double *__restrict__ gred, const int n_diag) {
+    if ((int)blockIdx.x < n_diag) rows_diag_block<ADD>(R, S, U, gc, gred, (int)blockIdx.x);
+    else rows_cross_block<ADD>(R, S, (int)blockIdx.x - n_diag);
 }
 
 // k_lin for a HEAVY point (a track no chunk holds): one workgroup, the point's observations in strides of 256.  Pass 1 sums
