@@ -1270,10 +1270,10 @@ __global__ __launch_bounds__(1024) void k_totals_state(int n, const double *__re
                                                        const double *__restrict__ cam_gmax) {
     __shared__ double rs[16], rm[16], rc[16];
     double s = 0.0, m = 0.0, mc = 0.0;
-    for (int i = threadIdx.x; i < n; i += 4096) {
-        double c[4], g[4];
+    for (int i = threadIdx.x; i < n; i += 8192) {   // (sixteen loads in flight per lane: the kernel is one workgroup's trips to memory)
+        double c[8], g[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             const int idx = i + u * 1024;
             const int j = idx < n ? idx : i;
             c[u] = ck_cost[j];
@@ -1281,7 +1281,7 @@ __global__ __launch_bounds__(1024) void k_totals_state(int n, const double *__re
             if (idx >= n) c[u] = g[u] = 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             s += c[u];
             m = fmax(m, g[u]);
         }
