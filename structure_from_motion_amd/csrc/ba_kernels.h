@@ -593,32 +593,6 @@ __device__ __forceinline__ bool spd6_inverse(const double *__restrict__ Ain, dou
 // The build kernels linearise in the local rotation tangent (load_aux_local).  This brings the accumulated reduced
 // system to the rvec parameters the solver steps in, once per build pass: with D = diag(Jl, I) per camera,
 // U = D^T U' D, g = D^T g', S_ij = D_i^T S'_ij D_j.  One thread per upper block, then one per free camera.
-__device__ __forceinline__ void apply_jl_block(int t, const long long *__restrict__ keys, const int *__restrict__ free_cam,
-                                               const double *__restrict__ aux, double *__restrict__ S) {
-    const int i = (int)(keys[t] >> 32), j = (int)(keys[t] & 0xffffffff);
-    const double *Ji = aux + (size_t)free_cam[i] * BA_CAM_AUX + 9, *Jj = aux + (size_t)free_cam[j] * BA_CAM_AUX + 9;
-    double *blk = &S[(size_t)t * 36];
-    double B[36], ji[9], jj[9];
-#pragma unroll
-    for (int k = 0; k < 36; ++k) B[k] = blk[k];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) { ji[k] = Ji[k]; jj[k] = Jj[k]; }
-    double T3[18];  // Ji^T * (top three rows)
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 6; ++c) T3[r * 6 + c] = ji[r] * B[c] + ji[3 + r] * B[6 + c] + ji[6 + r] * B[12 + c];
-#pragma unroll
-    for (int k = 0; k < 18; ++k) B[k] = T3[k];
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {  // (left three columns) * Jj
-        const double b0 = B[r * 6], b1 = B[r * 6 + 1], b2 = B[r * 6 + 2];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) B[r * 6 + c] = b0 * jj[c] + b1 * jj[3 + c] + b2 * jj[6 + c];
-    }
-#pragma unroll
-    for (int k = 0; k < 36; ++k) blk[k] = B[k];
-}
 __device__ __forceinline__ void apply_jl_camera(int f, const int *__restrict__ free_cam, const double *__restrict__ aux,
                                                 double *__restrict__ U, double *__restrict__ gc, double *__restrict__ gred) {
     const double *J = aux + (size_t)free_cam[f] * BA_CAM_AUX + 9;
@@ -656,12 +630,78 @@ __device__ __forceinline__ void apply_jl_camera(int f, const int *__restrict__ f
         g2[r] = jl[r] * b0 + jl[3 + r] * b1 + jl[6 + r] * b2;
     }
 }
-__global__ void k_apply_jl(int nf, int n_upper, const long long *__restrict__ keys, const int *__restrict__ free_cam,
+// S_ij <- Jl_i^T S_ij Jl_j (rotation parts) for the 64 blocks of a wave at once (t0 = the wave's first block, a multiple of 64).  A lane's block is 288
+// contiguous bytes, so the wave's blocks are ONE run of 18 KB: the wave copies the run into LDS with consecutive lanes on
+// consecutive 16-byte pieces (one request per 64-byte line where 36 strided 8-byte loads per lane asked for every line nine times
+// over), each lane transforms its block there (row stride 37 doubles: odd, no bank conflicts), and the run goes back the same way.
+// SKIP_DIAG: diagonal blocks are left alone (neither loaded nor stored: another thread owns them).
+constexpr int FIN_ROW = 37;
+template <bool SKIP_DIAG>
+__device__ __forceinline__ void apply_jl_run(const int t, const int n_upper, const long long *__restrict__ keys, const int *__restrict__ free_cam,
+                                             const double *__restrict__ aux, double *__restrict__ S, double *__restrict__ sBw,
+                                             unsigned char *__restrict__ sSkipw) {
+    const int lane = threadIdx.x & 63, t0 = t - lane;
+    const bool isblk = t < n_upper;
+    const long long key = keys[isblk ? t : t0];
+    const int i = (int)(key >> 32), j = (int)(key & 0xffffffff);
+    const bool mine = isblk && !(SKIP_DIAG && i == j);
+    sSkipw[lane] = mine ? 0 : 1;
+    // (the two cameras' left Jacobians: requested before the run is copied)
+    const double *Ji = aux + (size_t)free_cam[i] * BA_CAM_AUX + 9, *Jj = aux + (size_t)free_cam[j] * BA_CAM_AUX + 9;
+    double ji[9], jj[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { ji[k] = Ji[k]; jj[k] = Jj[k]; }
+    wave_lds_sync();
+    double *run = S + (size_t)t0 * 36;
+    double2 piece[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) {
+        const int idx = lane + 64 * k, b = idx / 18;
+        piece[k] = sSkipw[b] ? make_double2(0.0, 0.0) : reinterpret_cast<const double2 *>(run)[idx];
+    }
+#pragma unroll
+    for (int k = 0; k < 18; ++k) {
+        const int idx = lane + 64 * k, b = idx / 18, c = idx - b * 18;
+        sBw[b * FIN_ROW + 2 * c] = piece[k].x;
+        sBw[b * FIN_ROW + 2 * c + 1] = piece[k].y;
+    }
+    wave_lds_sync();
+    if (mine) {
+        double *blk = &sBw[lane * FIN_ROW];
+        double B[36];
+#pragma unroll
+        for (int k = 0; k < 36; ++k) B[k] = lds_f64(blk + k);
+        double T3[18];  // Ji^T * (top three rows)
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) T3[r * 6 + c] = ji[r] * B[c] + ji[3 + r] * B[6 + c] + ji[6 + r] * B[12 + c];
+#pragma unroll
+        for (int k = 0; k < 18; ++k) B[k] = T3[k];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {  // (left three columns) * Jj
+            const double b0 = B[r * 6], b1 = B[r * 6 + 1], b2 = B[r * 6 + 2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) B[r * 6 + c] = b0 * jj[c] + b1 * jj[3 + c] + b2 * jj[6 + c];
+        }
+#pragma unroll
+        for (int k = 0; k < 36; ++k) blk[k] = B[k];
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < 18; ++k) {
+        const int idx = lane + 64 * k, b = idx / 18, c = idx - b * 18;
+        if (!sSkipw[b]) reinterpret_cast<double2 *>(run)[idx] = make_double2(sBw[b * FIN_ROW + 2 * c], sBw[b * FIN_ROW + 2 * c + 1]);
+    }
+}
+__global__ __launch_bounds__(128) void k_apply_jl(int nf, int n_upper, const long long *__restrict__ keys, const int *__restrict__ free_cam,
                            const double *__restrict__ aux, double *__restrict__ S, double *__restrict__ U,
                            double *__restrict__ gc, double *__restrict__ gred) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n_upper) apply_jl_block(t, keys, free_cam, aux, S);
-    else if (t < n_upper + nf) apply_jl_camera(t - n_upper, free_cam, aux, U, gc, gred);
+    __shared__ __attribute__((aligned(16))) double sB[2][64 * FIN_ROW];
+    __shared__ unsigned char sSkip[2][64];
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, w = threadIdx.x >> 6;
+    if (t - (int)(threadIdx.x & 63) < n_upper) apply_jl_run<false>(t, n_upper, keys, free_cam, aux, S, sB[w], sSkip[w]);
+    if (t >= n_upper && t < n_upper + nf) apply_jl_camera(t - n_upper, free_cam, aux, U, gc, gred);
 }
 
 __device__ __forceinline__ void finalize_camera(int f, const double *__restrict__ U, const double *__restrict__ gc, double *__restrict__ gred,
@@ -716,7 +756,7 @@ __global__ void k_finalize(int nf, const double *__restrict__ U, const double *_
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f < nf) finalize_camera(f, U, gc, gred, S, diag_slot, Minv, cam_gmax, st);
 }
-// apply_jl_block (diagonal block) + apply_jl_camera + finalize_camera of ONE camera with everything kept in registers
+// the block transform of apply_jl_run (diagonal block) + apply_jl_camera + finalize_camera of ONE camera with everything kept in registers
 // between the three: every operand is requested once, up front, and every result stored once -- the three functions one
 // after the other wait for their own stores to come back from memory three times (the camera threads' chain of
 // dependent round trips set the time of k_apply_finalize: 18 us).  Same arithmetic, same order.
@@ -813,74 +853,15 @@ __device__ __forceinline__ void apply_finalize_camera(int f, const int *__restri
 
 // k_apply_jl and k_finalize in one launch (single-GPU build pass: nothing has to happen between them).  A camera's
 // thread transforms its own diagonal block (the block threads leave the diagonal keys alone) and finalises it.
-// One thread per upper block of S, then one per free camera.  A lane's block is 288 contiguous bytes, so a wave's 64 blocks are
-// ONE run of 18 KB: the wave copies the run into LDS with consecutive lanes on consecutive 16-byte pieces (one request per
-// 64-byte line where 36 strided 8-byte loads per lane asked for every line nine times over), each lane transforms its block there
-// (row stride 37 doubles: odd, no bank conflicts), and the run goes back the same way.  Diagonal blocks belong to the camera
-// threads (apply_finalize_camera) and are neither loaded nor stored here.
-constexpr int FIN_ROW = 37;
+// One thread per upper block of S (apply_jl_run; the diagonal blocks belong to the camera threads), then one per free camera.
 __global__ __launch_bounds__(128) void k_apply_finalize(int nf, int n_upper, const long long *__restrict__ keys, const int *__restrict__ free_cam,
                                  const double *__restrict__ aux, double *__restrict__ S, double *__restrict__ U,
                                  double *__restrict__ gc, double *__restrict__ gred, const int *__restrict__ diag_slot,
                                  double *__restrict__ cam_gmax, const LmState *__restrict__ st) {
     __shared__ __attribute__((aligned(16))) double sB[2][64 * FIN_ROW];
     __shared__ unsigned char sSkip[2][64];
-    const int t = blockIdx.x * blockDim.x + threadIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int t0 = t - lane;                       // first block of this wave's run
-    if (t0 < n_upper) {
-        const bool isblk = t < n_upper;
-        const long long key = keys[isblk ? t : t0];
-        const int i = (int)(key >> 32), j = (int)(key & 0xffffffff);
-        const bool mine = isblk && i != j;
-        sSkip[w][lane] = mine ? 0 : 1;
-        // (the two cameras' left Jacobians: requested before the run is copied)
-        const double *Ji = aux + (size_t)free_cam[i] * BA_CAM_AUX + 9, *Jj = aux + (size_t)free_cam[j] * BA_CAM_AUX + 9;
-        double ji[9], jj[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) { ji[k] = Ji[k]; jj[k] = Jj[k]; }
-        wave_lds_sync();
-        double *run = S + (size_t)t0 * 36;
-        double2 piece[18];
-#pragma unroll
-        for (int k = 0; k < 18; ++k) {
-            const int idx = lane + 64 * k, b = idx / 18;
-            piece[k] = sSkip[w][b] ? make_double2(0.0, 0.0) : reinterpret_cast<const double2 *>(run)[idx];
-        }
-#pragma unroll
-        for (int k = 0; k < 18; ++k) {
-            const int idx = lane + 64 * k, b = idx / 18, c = idx - b * 18;
-            sB[w][b * FIN_ROW + 2 * c] = piece[k].x;
-            sB[w][b * FIN_ROW + 2 * c + 1] = piece[k].y;
-        }
-        wave_lds_sync();
-        if (mine) {
-            double *blk = &sB[w][lane * FIN_ROW];
-            double B[36];
-#pragma unroll
-            for (int k = 0; k < 36; ++k) B[k] = lds_f64(blk + k);
-            double T3[18];  // Ji^T * (top three rows)
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int c = 0; c < 6; ++c) T3[r * 6 + c] = ji[r] * B[c] + ji[3 + r] * B[6 + c] + ji[6 + r] * B[12 + c];
-#pragma unroll
-            for (int k = 0; k < 18; ++k) B[k] = T3[k];
-#pragma unroll
-            for (int r = 0; r < 6; ++r) {  // (left three columns) * Jj
-                const double b0 = B[r * 6], b1 = B[r * 6 + 1], b2 = B[r * 6 + 2];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) B[r * 6 + c] = b0 * jj[c] + b1 * jj[3 + c] + b2 * jj[6 + c];
-            }
-#pragma unroll
-            for (int k = 0; k < 36; ++k) blk[k] = B[k];
-        }
-        wave_lds_sync();
-#pragma unroll
-        for (int k = 0; k < 18; ++k) {
-            const int idx = lane + 64 * k, b = idx / 18, c = idx - b * 18;
-            if (!sSkip[w][b]) reinterpret_cast<double2 *>(run)[idx] = make_double2(sB[w][b * FIN_ROW + 2 * c], sB[w][b * FIN_ROW + 2 * c + 1]);
-        }
-    }
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, w = threadIdx.x >> 6;
+    if (t - (int)(threadIdx.x & 63) < n_upper) apply_jl_run<true>(t, n_upper, keys, free_cam, aux, S, sB[w], sSkip[w]);
     if (t >= n_upper && t < n_upper + nf) apply_finalize_camera(t - n_upper, free_cam, aux, S, U, gc, gred, diag_slot, cam_gmax, st);
 }
 
