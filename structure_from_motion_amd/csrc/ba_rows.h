@@ -27,6 +27,7 @@
 
 namespace ba {
 
+constexpr int CROSS_ROW = 37;   // doubles per block in the store staging of rows_cross_block (odd: no bank conflicts)
 constexpr int ROW_A = 16, ROW_B = 8, ROW_DOUBLES = ROW_A + ROW_B;   // rows of 128 B (one cache line per gather) + the camera-sum tails
 
 struct RowsArgs {
@@ -233,8 +234,35 @@ __device__ __forceinline__ void rows_cross_block(const RowsArgs &R, double *__re
     }
 #pragma unroll
     for (int k = 0; k < 36; ++k) acc[k] += dpp_f64<0xB1>(acc[k]);
+    const int slot = valid ? R.key_slot[key] : -1;
+    if (!ADD) {
+        // A wave whose 32 blocks sit side by side in S (the usual case: the keys are ascending, only a diagonal block in between
+        // breaks the run) stores them as ONE run of 9 KB through LDS, consecutive lanes on consecutive 16-byte pieces: 144 full
+        // lines instead of 18 store instructions of 64 scattered 8-byte pieces each.
+        __shared__ __attribute__((aligned(16))) double sRun[4][32 * CROSS_ROW];
+        const int lane = tid & 63, w = tid >> 6;
+        const int slot0 = __builtin_amdgcn_readfirstlane(slot);
+        if (__all(valid && slot == slot0 + (lane >> 1))) {
+            double *mine = &sRun[w][(lane >> 1) * CROSS_ROW + 18 * half];
+            if (half == 0) {
+#pragma unroll
+                for (int k = 0; k < 18; ++k) mine[k] = -acc[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 18; ++k) mine[k] = -acc[18 + k];
+            }
+            wave_lds_sync();
+            double2 *run = reinterpret_cast<double2 *>(S + (size_t)slot0 * 36);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int idx = lane + 64 * k, b = idx / 18, c = idx - b * 18;
+                run[idx] = make_double2(sRun[w][b * CROSS_ROW + 2 * c], sRun[w][b * CROSS_ROW + 2 * c + 1]);
+            }
+            return;
+        }
+    }
     if (valid) {
-        double *d = S + (size_t)R.key_slot[key] * 36;
+        double *d = S + (size_t)slot * 36;
         if (half == 0) {
 #pragma unroll
             for (int k = 0; k < 18; ++k) d[k] = (ADD ? d[k] : 0.0) - acc[k];
