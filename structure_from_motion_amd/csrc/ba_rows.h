@@ -235,10 +235,10 @@ __device__ __forceinline__ void rows_cross_block(const RowsArgs &R, double *__re
 #pragma unroll
     for (int k = 0; k < 36; ++k) acc[k] += dpp_f64<0xB1>(acc[k]);
     const int slot = valid ? R.key_slot[key] : -1;
-    if (!ADD) {
+    {
         // A wave whose 32 blocks sit side by side in S (the usual case: the keys are ascending, only a diagonal block in between
         // breaks the run) stores them as ONE run of 9 KB through LDS, consecutive lanes on consecutive 16-byte pieces: 144 full
-        // lines instead of 18 store instructions of 64 scattered 8-byte pieces each.
+        // lines instead of 18 store instructions of 64 scattered 8-byte pieces each (ADD: read-modify-write of the run, the same way).
         __shared__ __attribute__((aligned(16))) double sRun[4][32 * CROSS_ROW];
         const int lane = tid & 63, w = tid >> 6;
         const int slot0 = __builtin_amdgcn_readfirstlane(slot);
@@ -256,7 +256,8 @@ __device__ __forceinline__ void rows_cross_block(const RowsArgs &R, double *__re
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
                 const int idx = lane + 64 * k, b = idx / 18, c = idx - b * 18;
-                run[idx] = make_double2(sRun[w][b * CROSS_ROW + 2 * c], sRun[w][b * CROSS_ROW + 2 * c + 1]);
+                const double2 was = ADD ? run[idx] : make_double2(0.0, 0.0);
+                run[idx] = make_double2(was.x + sRun[w][b * CROSS_ROW + 2 * c], was.y + sRun[w][b * CROSS_ROW + 2 * c + 1]);
             }
             return;
         }
