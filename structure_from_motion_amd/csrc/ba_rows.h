@@ -27,6 +27,7 @@
 
 namespace ba {
 
+constexpr int LIN_ROW = 17;     // doubles per observation in k_lin's store staging (odd)
 constexpr int CROSS_ROW = 37;   // doubles per block in the store staging of rows_cross_block (odd: no bank conflicts)
 constexpr int ROW_A = 16, ROW_B = 8, ROW_DOUBLES = ROW_A + ROW_B;   // rows of 128 B (one cache line per gather) + the camera-sum tails
 
@@ -45,7 +46,8 @@ struct RowsArgs {
 
 template <int LOSS>
 __global__ __launch_bounds__(CHUNK_OBS) void k_lin(const BuildArgs A, double *__restrict__ rows, double *__restrict__ tails) {
-    __shared__ __attribute__((aligned(16))) double sV[CHUNK_OBS * 9];      // per observation: its part of V (6), g_p (3)
+    // per observation: its part of V (6), g_p (3); afterwards the staging of the rows and tails on their way out (LIN_ROW per lane)
+    __shared__ __attribute__((aligned(16))) double sV[CHUNK_OBS * LIN_ROW];
     __shared__ __attribute__((aligned(16))) double sP[CHUNK_PTS * 9];      // per point: L^-1 (6), u (3)
     __shared__ int sStart[CHUNK_PTS + 1];                                  // first lane of each point's observations
     __shared__ double sRed[8];
@@ -151,26 +153,51 @@ __global__ __launch_bounds__(CHUNK_OBS) void k_lin(const BuildArgs A, double *__
         A.ck_cost[ck] = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
         A.ck_gmax[ck] = fmax(fmax(sRed[4], sRed[5]), fmax(sRed[6], sRed[7]));
     }
-    if (act && free_cam) {
-        const double *vp = &sP[lp * 9];
-        const double i00 = vp[0], i10 = vp[1], i11 = vp[2], i20 = vp[3], i21 = vp[4], i22 = vp[5];
-        const double u0 = vp[6], u1 = vp[7], u2 = vp[8];
-        double t[9];
+    // rows and tails leave through LDS: a wave's 64 rows are ONE run of 8 KB (its tails one of 4 KB), stored with consecutive lanes
+    // on consecutive 16-byte pieces.  (sV is free: the per-point gather is behind the barrier above.)  Observations of fixed
+    // cameras get zeros: no entry ever names them.
+    {
+        double t[9], w0 = 0.0, w1 = 0.0, w2 = 0.0;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            t[i * 3] = Wt[i * 3] * i00;
-            t[i * 3 + 1] = Wt[i * 3] * i10 + Wt[i * 3 + 1] * i11;
-            t[i * 3 + 2] = Wt[i * 3] * i20 + Wt[i * 3 + 1] * i21 + Wt[i * 3 + 2] * i22;
+        for (int k = 0; k < 9; ++k) t[k] = 0.0;
+        const bool on = act && free_cam;
+        if (on) {
+            const double *vp = &sP[lp * 9];
+            const double i00 = vp[0], i10 = vp[1], i11 = vp[2], i20 = vp[3], i21 = vp[4], i22 = vp[5];
+            const double u0 = vp[6], u1 = vp[7], u2 = vp[8];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                t[i * 3] = Wt[i * 3] * i00;
+                t[i * 3 + 1] = Wt[i * 3] * i10 + Wt[i * 3 + 1] * i11;
+                t[i * 3 + 2] = Wt[i * 3] * i20 + Wt[i * 3 + 1] * i21 + Wt[i * 3 + 2] * i22;
+            }
+            w0 = t[0] * u0 + t[1] * u1 + t[2] * u2; w1 = t[3] * u0 + t[4] * u1 + t[5] * u2; w2 = t[6] * u0 + t[7] * u1 + t[8] * u2;
         }
-        const double w0 = t[0] * u0 + t[1] * u1 + t[2] * u2, w1 = t[3] * u0 + t[4] * u1 + t[5] * u2,
-                     w2 = t[6] * u0 + t[7] * u1 + t[8] * u2;
-        double2 *d = reinterpret_cast<double2 *>(rows + (size_t)oo * ROW_A);
-        d[0] = make_double2(t[0], t[1]); d[1] = make_double2(t[2], t[3]); d[2] = make_double2(t[4], t[5]);
-        d[3] = make_double2(t[6], t[7]); d[4] = make_double2(t[8], Yr[0]); d[5] = make_double2(Yr[1], Yr[2]);
-        d[6] = make_double2(w0, w1); d[7] = make_double2(w2, 0.0);
-        double2 *q = reinterpret_cast<double2 *>(tails + (size_t)oo * ROW_B);
-        q[0] = make_double2(tail[0], tail[1]); q[1] = make_double2(tail[2], tail[3]);
-        q[2] = make_double2(tail[4], tail[5]); q[3] = make_double2(tail[6], tail[7]);
+        const int lane = tid & 63, wv = tid >> 6;
+        const int n_w = nobs - wv * 64 < 64 ? nobs - wv * 64 : 64;      // observations of this wave (may be <= 0)
+        double *stg = &sV[wv * 64 * LIN_ROW];
+        double *mine = stg + lane * LIN_ROW;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) mine[k] = t[k];
+        mine[9] = on ? Yr[0] : 0.0; mine[10] = on ? Yr[1] : 0.0; mine[11] = on ? Yr[2] : 0.0;
+        mine[12] = w0; mine[13] = w1; mine[14] = w2; mine[15] = 0.0;
+        wave_lds_sync();
+        double2 *out = reinterpret_cast<double2 *>(rows + (size_t)(ob + wv * 64) * ROW_A);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int idx = lane + 64 * k, b = idx >> 3, c = idx & 7;
+            if (b < n_w) out[idx] = make_double2(stg[b * LIN_ROW + 2 * c], stg[b * LIN_ROW + 2 * c + 1]);
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) mine[k] = on ? tail[k] : 0.0;
+        wave_lds_sync();
+        double2 *outt = reinterpret_cast<double2 *>(tails + (size_t)(ob + wv * 64) * ROW_B);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = lane + 64 * k, b = idx >> 2, c = idx & 3;
+            if (b < n_w) outt[idx] = make_double2(stg[b * LIN_ROW + 2 * c], stg[b * LIN_ROW + 2 * c + 1]);
+        }
     }
 }
 
