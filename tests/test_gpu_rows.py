@@ -224,7 +224,7 @@ def _landmarks_problem(n_cams, n_landmarks, seed=4):
 @pytest.mark.parametrize("loss", ["huber", "cauchy"])
 def test_heavy_points_through_the_entry_lists(gpu, mode, loss):
     """Landmarks seen by all 300 cameras next to ordinary street tracks.  In the chunk mode the chunks go through k_build and the
-    landmarks' pairs are ADDED from the global lists (k_lin_heavy, k_rows_diag / k_rows_cross); in the rows mode they sit in the
+    landmarks' pairs are ADDED from the global lists (k_lin_heavy, k_rows_schur<ADD>); in the rows mode they sit in the
     lists with everybody else.  Same reduced system as the oracle's either way."""
     p = _landmarks_problem(300, 4)
     lam = 1e-3
